@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the TRUE reference (imported from /root/reference)
+and writes small data-only fixtures under tests/golden/.
+
+TEST INFRASTRUCTURE ONLY.  Runs in the build container (the reference never
+travels to the GPU box); the fixtures it writes are plain data (inputs and
+expected outputs), never reference source.
+
+Usage (from any cwd; it chdirs to a scratch dir because importing
+alpha_zero/alpha_net.py does `mkdir ./datasets/iter3/` in the cwd):
+
+    python3 -B oracle/gen_golden.py tables
+    python3 -B oracle/gen_golden.py games   --games 64 --procs 8
+    python3 -B oracle/gen_golden.py mcts    --plies 6
+    python3 -B oracle/gen_golden.py net
+
+Fixture families:
+  tables.json        board geometry: neighbour order per cell, is_straight_line LUT,
+                     axial-distance classes, action-slot keys, core_index labels
+  games_*.json.gz    random-playout games: per ply the packed position, sorted legal
+                     list, next_move_tiles, sparse 56-plane encoding, state_key,
+                     terminal flag/winner and the action taken
+  mcts.json.gz       HivePlayer (SEARCH_THREADS=1, seeded numpy, stub evaluator)
+                     visit counts / chosen action
+  net.json           ChessNet seeded-init output checksums
+"""
+import argparse
+import gzip
+import json
+import os
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+GOLD = os.path.join(REPO, "tests", "golden")
+REF = "/root/reference"
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, "stubs"))
+os.chdir(tempfile.mkdtemp(prefix="hive_oracle_"))
+
+import numpy as np  # noqa: E402
+
+SLOT_TYPES = "QBBSSGGGAAA"
+
+
+def _new_game():
+    from settings import WIDTH, HEIGHT
+    from hive_engine.env_hive import GamePlay
+    return GamePlay(HEIGHT_MAP=HEIGHT - 100, WIDTH_MAP=WIDTH - 500)
+
+
+def _cell(tile):
+    return int(tile.index_xy[0]) * 12 + int(tile.index_xy[1])
+
+
+def snapshot(g, with_planes=True):
+    """Everything observable about the reference env at this ply, as plain ints."""
+    from settings import PIECE_WHITE, PIECE_BLACK
+    pos, lvl = [], []
+    for pset in (g.white_pieces_set, g.black_pieces_set):
+        for key, (tile, level, piece) in pset.items():
+            if tile.axial_coords == (99, 99):
+                pos.append(255)
+                lvl.append(0)
+            else:
+                pos.append(_cell(tile))
+                lvl.append(int(level))
+                assert tile.pieces[level] is piece
+    over = bool(g.game_is_over())
+    w = g.state.winner
+    rec = {
+        "t": int(g.state.turn),
+        "pos": pos,
+        "lvl": lvl,
+        "nmt": sorted(_cell(t) for t in g.next_move_tiles),
+        "legal": [int(a) for a in g.actions()],
+        "over": over,
+        "win": 0 if w is None else (1 if w == PIECE_WHITE else 2),
+        "key": g.state_key,
+    }
+    assert rec["legal"] == sorted(rec["legal"])
+    if with_planes:
+        planes = g.encode_board()
+        assert planes.shape == (12, 12, 56)
+        assert np.all(planes[:, :, 31] == g.state.turn)
+        pl = planes.copy()
+        pl[:, :, 31] = 0
+        nz = np.argwhere(pl != 0)
+        assert np.all(pl[pl != 0] == 1)
+        rec["planes"] = sorted(int((x * 12 + y) * 56 + p) for x, y, p in nz)
+    return rec
+
+
+def choose(g, rng, policy):
+    """Pick the next action.  Policies only bias WHICH legal move is taken so that
+    rarer situations (beetle stacks, surrounded queens, passes) show up."""
+    acts = g.actions()
+    if not acts:
+        return -1
+    if policy == "uniform" or rng.random() < 0.35:
+        return int(acts[rng.integers(len(acts))])
+    occ = {}
+    for pset in (g.white_pieces_set, g.black_pieces_set):
+        for key, (tile, level, piece) in pset.items():
+            if tile.axial_coords != (99, 99):
+                occ[_cell(tile)] = occ.get(_cell(tile), 0) + 1
+    if policy == "beetle":
+        cand = [a for a in acts if (a % 11) in (1, 2) and (a // 11) in occ]
+        if cand:
+            return int(cand[rng.integers(len(cand))])
+        cand = [a for a in acts if (a % 11) in (1, 2)]
+        if cand and rng.random() < 0.5:
+            return int(cand[rng.integers(len(cand))])
+    if policy == "attack":
+        eset = g.black_pieces_set if g.state.player() == 0 else g.white_pieces_set
+        qt = eset["<class 'pieces.Queen'>0"][0]
+        if qt.axial_coords != (99, 99):
+            near = {_cell(t) for t in qt.adjacent_tiles}
+            cand = [a for a in acts if (a // 11) in near]
+            if cand:
+                return int(cand[rng.integers(len(cand))])
+    return int(acts[rng.integers(len(acts))])
+
+
+def play_game(args):
+    seed, policy, with_planes = args
+    rng = np.random.default_rng(seed)
+    g = _new_game()
+    plies = []
+    while True:
+        rec = snapshot(g, with_planes)
+        if rec["over"] or g.state.turn >= 55:
+            rec["a"] = None
+            plies.append(rec)
+            break
+        a = choose(g, rng, policy)
+        rec["a"] = a
+        plies.append(rec)
+        g.move(a)
+    return {"seed": seed, "policy": policy, "plies": plies}
+
+
+def cmd_tables(_):
+    import move_checker as mc
+    g = _new_game()
+    tiles = [t for t in g.state.board_tiles if t.axial_coords != (99, 99)]
+    assert len(tiles) == 144
+    order = [_cell(t) for t in tiles]                      # board_tiles order (state_key order)
+    by_cell = {_cell(t): t for t in tiles}
+    nbr = [[_cell(a) for a in by_cell[c].adjacent_tiles] for c in range(144)]
+    core = [list(by_cell[c].core_index) for c in range(144)]
+    start = [c for c in range(144) if type(by_cell[c]).__name__ == "Start_Tile"]
+    line = []      # line[a] = list of b with is_straight_line(index_xy[a], index_xy[b])
+    dist1 = []     # ordered pairs whose effective dist == 1 (adjacent or axial distance 1)
+    distle1 = []   # ordered pairs a!=b whose effective dist is NOT > 1
+    for a in range(144):
+        ta = by_cell[a]
+        line.append([b for b in range(144)
+                     if mc.is_straight_line(ta.index_xy, by_cell[b].index_xy)])
+        for b in range(144):
+            tb = by_cell[b]
+            d = mc.axial_distance(ta.axial_coords, tb.axial_coords)
+            if ta in tb.adjacent_tiles:
+                d = 1
+            if d == 1:
+                dist1.append([a, b])
+            if a != b and not (d > 1):
+                distle1.append([a, b])
+    out = {
+        "board_order": order,
+        "nbr": nbr,
+        "core_index": core,
+        "start_cell": start,
+        "line": line,
+        "dist_eq_1_pairs": dist1,
+        "dist_not_gt_1_pairs": distle1,
+        "slot_keys": list(g.white_pieces_set.keys()),
+        "first_legal": [int(a) for a in g.actions()],
+        "piece_keys_white": [g.pieces_keys[v[2]] for v in g.white_pieces_set.values()],
+        "piece_keys_black": [g.pieces_keys[v[2]] for v in g.black_pieces_set.values()],
+    }
+    with open(os.path.join(GOLD, "tables.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("tables.json written; dist==1 pairs", len(dist1), "line pairs", sum(map(len, line)))
+
+
+def cmd_games(a):
+    import multiprocessing as mp
+    jobs = []
+    pols = ["uniform", "beetle", "attack"]
+    for i in range(a.games):
+        jobs.append((a.seed0 + i, pols[i % 3], not a.no_planes))
+    with mp.Pool(a.procs) as pool:
+        games = []
+        for k, gm in enumerate(pool.imap_unordered(play_game, jobs)):
+            games.append(gm)
+            print(f"[{k + 1}/{len(jobs)}] seed {gm['seed']} {gm['policy']} plies {len(gm['plies'])} "
+                  f"over={gm['plies'][-1]['over']} win={gm['plies'][-1]['win']}", flush=True)
+    games.sort(key=lambda x: x["seed"])
+    name = a.out or ("games_movegen.json.gz" if a.no_planes else "games_full.json.gz")
+    with gzip.open(os.path.join(GOLD, name), "wt", compresslevel=9) as f:
+        json.dump({"games": games}, f, separators=(",", ":"))
+    npos = sum(len(g["plies"]) for g in games)
+    print(name, "games", len(games), "positions", npos)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    sub.add_parser("tables")
+    pg = sub.add_parser("games")
+    pg.add_argument("--games", type=int, default=48)
+    pg.add_argument("--procs", type=int, default=8)
+    pg.add_argument("--seed0", type=int, default=0)
+    pg.add_argument("--no-planes", action="store_true")
+    pg.add_argument("--out", default=None)
+    a = ap.parse_args()
+    {"tables": cmd_tables, "games": cmd_games}[a.cmd](a)
