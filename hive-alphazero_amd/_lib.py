@@ -1,0 +1,91 @@
+"""Loader of libhive_hip.so (the C ABI of include/hive_abi.h) through ctypes.
+
+There is no CPU implementation behind this package: if the shared library is missing or no
+HIP device is visible, calls fail loudly (HiveError) instead of falling back.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(_HERE, "libhive_hip.so")
+
+HIVE_CELLS = 144
+HIVE_PIECES = 22
+HIVE_ACTIONS = 1584
+HIVE_PLANES = 56
+HIVE_MASK_WORDS = 50
+HIVE_LIST_CAP = 256
+HIVE_IN_HAND = 255
+BOARD_BYTES = 64
+HISTORY_BYTES = 384
+
+F32, F16, BF16 = 0, 1, 2
+HWC, CHW = 0, 1
+
+# every symbol include/hive_abi.h declares (tests/test_abi_symbols.py checks the header against this)
+ABI_SYMBOLS = [
+    "hive_last_error", "hive_version", "hive_device_count", "hive_batch_create", "hive_batch_destroy",
+    "hive_batch_size", "hive_batch_set_stream", "hive_batch_reset", "hive_batch_step",
+    "hive_batch_illegal_count", "hive_batch_legal", "hive_batch_encode", "hive_batch_terminal",
+    "hive_batch_export", "hive_batch_import", "hive_movegen_launch", "hive_encode_launch",
+]
+
+
+class HiveError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"hive ABI error {code}: {msg}")
+        self.code = code
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 into libhive_hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "hive_abi.h"))
+    stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _CSRC, "-s"] + (["-B"] if force else []))
+    return SO_PATH
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library and declare the signatures.  Raises if the .so is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise HiveError(-2, f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(the HIP extension is mandatory, there is no CPU path)")
+    L = ctypes.CDLL(SO_PATH)
+    vp, i32 = ctypes.c_void_p, ctypes.c_int
+    L.hive_last_error.restype = ctypes.c_char_p
+    L.hive_version.restype = ctypes.c_char_p
+    L.hive_device_count.restype = i32
+    L.hive_batch_create.argtypes = [i32, i32, ctypes.POINTER(vp)]
+    L.hive_batch_destroy.argtypes = [vp]
+    L.hive_batch_size.argtypes = [vp]
+    L.hive_batch_set_stream.argtypes = [vp, vp]
+    L.hive_batch_reset.argtypes = [vp, vp, i32]
+    L.hive_batch_step.argtypes = [vp, vp, i32]
+    L.hive_batch_illegal_count.argtypes = [vp, ctypes.POINTER(ctypes.c_int64)]
+    L.hive_batch_legal.argtypes = [vp, vp, vp, vp]
+    L.hive_batch_encode.argtypes = [vp, vp, i32, i32]
+    L.hive_batch_terminal.argtypes = [vp, vp, vp]
+    L.hive_batch_export.argtypes = [vp, vp, vp]
+    L.hive_batch_import.argtypes = [vp, vp, vp]
+    L.hive_movegen_launch.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.hive_encode_launch.argtypes = [vp, vp, i32, vp, i32, i32, vp]
+    L.hive_debug_tables.argtypes = [vp, vp, vp]
+    for name in ABI_SYMBOLS:
+        getattr(L, name)
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise HiveError(rc, load().hive_last_error().decode())

@@ -1,0 +1,882 @@
+// hive_env.hip -- batched Hive env kernels for gfx950 (MI355X) + the C ABI of include/hive_abi.h.
+//
+// Work decomposition: one workgroup owns G = 64 boards; wave w of the
+// workgroup owns piece slot w of all 64 boards, so every wave runs exactly one piece type
+// (no type divergence) and lane l of every wave works on board l.  The boards' packed
+// records, occupancy / top-colour bitboards and the is_straight_line LUT are staged in LDS;
+// per-piece destination bitboards go back to LDS and are turned into the 1584-bit legal mask
+// with 25 wave ballots per board (mbcnt prefix sums give the sorted id list).
+//
+// Reference semantics implemented here (paths relative to the reference root):
+//   env_hive.py:196-304   pre_actions / get_actions / encode_action
+//   env_hive.py:320-485   make_state_value / mini_black_actions (56 planes)
+//   env_hive.py:99-171    move
+//   move_checker.py:9-265 is_valid_move and the rule helpers
+//   pieces.py:35-158      per-piece move_is_valid
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <type_traits>
+#include <cstring>
+#include <string>
+
+#include "../../include/hive_abi.h"
+#include "hive_bb.hpp"
+#include "hive_tables.hpp"
+
+namespace hive {
+
+__device__ const Tables d_tables = kTables;
+
+constexpr int NW = 11;                 // waves per workgroup = piece slots per colour
+constexpr unsigned kHand = 255u;
+
+enum PieceType { T_QUEEN = 0, T_BEETLE = 1, T_SPIDER = 2, T_GRASS = 3, T_ANT = 4 };
+__device__ __forceinline__ int slot_type(int slot)
+{
+    // Q B B S S G G G A A A
+    return slot == 0 ? T_QUEEN : slot < 3 ? T_BEETLE : slot < 5 ? T_SPIDER : slot < 8 ? T_GRASS : T_ANT;
+}
+__device__ __forceinline__ int slot_group_start(int slot)
+{
+    return slot == 0 ? 0 : slot < 3 ? 1 : slot < 5 ? 3 : slot < 8 ? 5 : 8;
+}
+
+// ------------------------------------------------------------------ LDS image
+// FULL = false: G = 64 boards per workgroup, lane = board, wave = slot of the side to move.
+// FULL = true : G = 32 boards per workgroup, lanes 0-31 = white piece, lanes 32-63 = black piece
+//               of slot `wave` (both colours are needed by the planes); still one type per wave.
+template <bool FULL>
+struct Smem {
+    static constexpr int G = FULL ? 32 : 64;
+    static constexpr int ND = FULL ? 22 : 11;
+    uint32_t state[G][16];       // HiveBoard records
+    uint32_t occ[G][6];          // cells with at least one piece
+    uint32_t topw[G][6];         // cells whose top piece is white
+    uint32_t nocc[G][6];         // neighbours(occ)
+    uint32_t line[kCells][6];    // is_straight_line LUT
+    uint8_t nbr[kCells][8];      // adjacent_tiles order LUT
+    uint32_t dest[ND][G][6];     // destination board of piece d on board g
+    unsigned long long feat[FULL ? G : 1][FULL ? kCells : 1];   // 56 feature bits per cell
+};
+
+__device__ __forceinline__ BB lds_bb(const uint32_t *p)
+{
+    BB r;
+    HIVE_UNROLL for (int i = 0; i < 6; ++i) r.w[i] = p[i];
+    return r;
+}
+__device__ __forceinline__ void lds_store_bb(uint32_t *p, BB v)
+{
+    HIVE_UNROLL for (int i = 0; i < 6; ++i) p[i] = v.w[i];
+}
+__device__ __forceinline__ unsigned state_byte(const uint32_t *st, unsigned idx)
+{
+    return reinterpret_cast<const uint8_t *>(st)[idx];
+}
+__device__ __forceinline__ bool lds_test(const uint32_t *bbp, unsigned cell)
+{
+    unsigned wi, bit;
+    cell_word_bit(cell, wi, bit);
+    return (bbp[wi] >> bit) & 1u;
+}
+
+// per-direction source boards -> union of the shifted boards (d0..d5 = R UR U L DL D)
+__device__ __forceinline__ BB shift_dirs(BB a0, BB a1, BB a2, BB a3, BB a4, BB a5)
+{
+    BB u2 = bb_up(a2), d5 = bb_down(a5);
+    BB r = bb_right(bb_or(a0, bb_up(a1)));
+    BB l = bb_left(bb_or(a3, bb_down(a4)));
+    BB o;
+    HIVE_UNROLL for (int i = 0; i < 6; ++i) o.w[i] = u2.w[i] | d5.w[i] | r.w[i] | l.w[i];
+    return o;
+}
+
+// move_checker.py:106-137
+__device__ __forceinline__ bool obeys_queen_by_4(unsigned turn, int nq, int first_color, bool mover_queen,
+                                                 int mover_color)
+{
+    if (nq == 2) return true;
+    if (nq == 0)
+        return (turn == 7 && mover_queen && mover_color == 0) || (turn == 8 && mover_queen && mover_color == 1);
+    return (first_color == 0 && turn == 7) || (first_color == 1 && turn == 7 && mover_queen) ||
+           (first_color == 1 && turn == 8) || (first_color == 0 && turn == 8 && mover_queen);
+}
+
+struct PieceInfo {
+    BB D;            // final destination set
+    unsigned cell;   // kHand if in hand
+    unsigned lvl, h;
+    bool on_board, on_top, pinned;
+};
+
+// Everything one (board, piece) lane computes.  `type` and the loops' trip tests are wave-uniform.
+// own == true : get_actions semantics (env_hive.py:207-285)
+// own == false: mini_black_actions semantics for an enemy piece (env_hive.py:449-485)
+__device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint32_t *occ_p, const uint32_t *topw_p,
+                                                 const uint32_t *nocc_p, const uint32_t (*line)[6], int q,
+                                                 int type, bool own, bool valid)
+{
+    PieceInfo out;
+    const unsigned turn = state_byte(st, 33);
+    const unsigned mode = state_byte(st, 34) & 3u;
+    const int stm = (turn & 1u) ? 0 : 1;
+    const int color = q >= 11 ? 1 : 0, slot = q - 11 * color;
+    const unsigned c = state_byte(st, (unsigned)q);
+    const bool in_hand = c >= (unsigned)kCells;
+
+    // stack height of the mover's cell and the mover's index in it (env_hive.py:213)
+    uint32_t pw[6];
+    HIVE_UNROLL for (int i = 0; i < 6; ++i) pw[i] = st[i];
+    unsigned h = 0;
+    HIVE_UNROLL for (int r = 0; r < 22; ++r) h += (((pw[r >> 2] >> ((r & 3) * 8)) & 0xFFu) == c) ? 1u : 0u;
+    const unsigned lb = state_byte(st, 22u + ((unsigned)q >> 1));
+    const unsigned lv = (q & 1) ? (lb >> 4) : (lb & 15u);
+    const bool on_board = valid && !in_hand;
+    const bool on_top = on_board && (lv + 1u == h);
+    const bool stacked = h > 1u;
+
+    const bool wq = (pw[0] & 0xFFu) < (unsigned)kCells;            // white queen placed
+    const bool bq = ((pw[2] >> 24) & 0xFFu) < (unsigned)kCells;    // black queen (piece 11) placed
+    const int nq = (wq ? 1 : 0) + (bq ? 1 : 0);
+    const int first_color = wq ? 0 : 1;
+    const bool stm_queen = stm == 0 ? wq : bq;
+
+    const BB occ = lds_bb(occ_p), nocc = lds_bb(nocc_p);
+    const BB srcbit = bb_bit(on_board ? c : 255u);
+    const BB occp = (on_board && !stacked) ? bb_xor(occ, srcbit) : occ;
+
+    // ---- one-hive test (move_checker.py:58-83 / env_hive.py:509-530): flood the hive without
+    // the mover from one of its neighbours until every neighbour is reached or nothing grows.
+    BB target = bb_and(bb_neighbours(srcbit), occp);
+    bool pinned = on_top && !stacked && !bb_any(target);    // lone piece: empty board => False
+    bool act = on_top && !stacked && bb_any(target);
+    BB reach = bb_lowest(target);
+    while (__any(act)) {
+        if (act) {
+            BB nx = bb_or(reach, bb_and(bb_neighbours(reach), occp));
+            bool covered = !bb_any(bb_andn(target, nx));
+            bool fixed = bb_eq(nx, reach);
+            reach = nx;
+            if (covered) act = false;
+            else if (fixed) { act = false; pinned = true; }
+        }
+    }
+    const bool movable = on_top && !pinned;
+
+    // ---- piece rule (pieces.py) on the board with the mover lifted
+    BB rule = bb_zero();
+    if (type == T_GRASS) {
+        // pieces.py:128-158: flood from src through occupied cells on a "line" from src
+        unsigned lc = on_board ? c : 0u;
+        BB L = lds_bb(line[lc]);
+        BB Lo = bb_and(L, occ);
+        BB V = srcbit;
+        bool ga = movable;
+        while (__any(ga)) {
+            if (ga) {
+                BB nx = bb_or(V, bb_and(bb_neighbours(V), Lo));
+                if (bb_eq(nx, V)) ga = false;
+                V = nx;
+            }
+        }
+        rule = bb_andn(bb_and(bb_andn(bb_neighbours(V), occ), L), bb_neighbours(srcbit));
+    } else {
+        SlideCtx ctx = make_slide_ctx(occp);
+        if (type == T_QUEEN) {
+            rule = slide_step(ctx, srcbit);                       // pieces.py:35-44
+        } else if (type == T_ANT) {
+            BB R = srcbit;                                        // pieces.py:59-63, move_checker.py:217-246
+            bool aa = movable;
+            while (__any(aa)) {
+                if (aa) {
+                    BB nx = bb_or(R, slide_step(ctx, R));
+                    if (bb_eq(nx, R)) aa = false;
+                    R = nx;
+                }
+            }
+            rule = bb_andn(R, srcbit);
+        } else {
+            // both flanks occupied (k == 2) per direction
+            BB S[6];
+            occupancy_views(occp, S);
+            BB b0 = bb_and(S[5], S[1]), b1 = bb_and(S[0], S[2]), b2 = bb_and(S[1], S[3]);
+            BB b3 = bb_and(S[2], S[4]), b4 = bb_and(S[3], S[5]), b5 = bb_and(S[4], S[0]);
+            if (type == T_SPIDER) {
+                // pieces.py:78-85: simple path of exactly three k==1 steps, then the direct-hop veto
+                BB A = slide_step(ctx, srcbit);
+                BB acc = bb_zero();
+                bool sa = movable && bb_any(A);
+                while (__any(sa)) {
+                    if (sa) {
+                        BB a = bb_lowest(A);
+                        A = bb_andn(A, a);
+                        BB Bs = bb_andn(slide_step(ctx, a), srcbit);
+                        BB Cs = bb_andn(bb_andn(slide_step(ctx, Bs), srcbit), a);
+                        acc = bb_or(acc, Cs);
+                        sa = bb_any(A);
+                    }
+                }
+                BB veto = shift_dirs(bb_and(srcbit, b0), bb_and(srcbit, b1), bb_and(srcbit, b2),
+                                     bb_and(srcbit, b3), bb_and(srcbit, b4), bb_and(srcbit, b5));
+                rule = bb_andn(acc, veto);
+            } else {
+                // Beetle, pieces.py:100-113 + move_checker.py:201-209
+                BB P = bb_neighbours(srcbit);
+                BB Q1 = slide_raw(ctx, srcbit);
+                BB k0[6];
+                k0[0] = bb_andn(bb_andn(srcbit, ctx.cs[0]), b0);
+                k0[1] = bb_andn(bb_andn(srcbit, ctx.cs[1]), b1);
+                k0[2] = bb_andn(bb_andn(srcbit, ctx.cs[2]), b2);
+                k0[3] = bb_andn(bb_andn(srcbit, ctx.cs[3]), b3);
+                k0[4] = bb_andn(bb_andn(srcbit, ctx.cs[4]), b4);
+                k0[5] = bb_andn(bb_andn(srcbit, ctx.cs[5]), b5);
+                BB Q0 = shift_dirs(k0[0], k0[1], k0[2], k0[3], k0[4], k0[5]);
+                rule = bb_or(bb_or(bb_and(P, occ), Q1), bb_and(Q0, ctx.nocc));
+                if (stacked) rule = bb_or(rule, P);
+            }
+        }
+    }
+
+    // ---- next_move_tiles (env_hive.py:66-69,150-161)
+    const BB empty_adj = bb_andn(nocc, occ);
+    BB nmt = empty_adj;
+    if (mode == 1u) nmt = bb_bit((unsigned)kStartCell);
+    else if (mode == 2u) nmt = bb_and(empty_adj, bb_bit((unsigned)kTurn2Cell));
+
+    // ---- turn gating (move_checker.py:38-55)
+    bool gate = true;
+    if (turn >= 3u && turn <= 6u) gate = in_hand || stm_queen;                      // queen_is_on_board
+    else if (turn == 7u || turn == 8u) gate = obeys_queen_by_4(turn, nq, first_color, type == T_QUEEN, color);
+
+    BB D = bb_zero();
+    if (valid && in_hand) {
+        if (own) {
+            // only the first in-hand piece of each type emits placements (env_hive.py:218-219)
+            bool first = true;
+            const int g0 = slot_group_start(slot);
+            HIVE_UNROLL for (int r = 0; r < 22; ++r) {
+                int rs = r >= 11 ? r - 11 : r, rc = r >= 11 ? 1 : 0;
+                bool earlier_same = rc == color && rs >= g0 && rs < slot;
+                if (earlier_same && ((pw[r >> 2] >> ((r & 3) * 8)) & 0xFFu) >= (unsigned)kCells) first = false;
+            }
+            if (first) {
+                BB base = bb_andn(nmt, occ);
+                if (turn == 1u) D = bb_and(base, bb_bit((unsigned)kStartCell));
+                else if (turn == 2u) D = bb_and(base, nocc);
+                else if (gate) {
+                    // placement_is_allowed (move_checker.py:168-179): no neighbour topped by the other colour
+                    BB topw = lds_bb(topw_p);
+                    BB top_enemy = color == 0 ? bb_andn(occ, topw) : topw;
+                    D = bb_andn(bb_and(base, nocc), bb_neighbours(top_enemy));
+                }
+            }
+        }
+    } else if (movable) {
+        const bool adjacent_domain = (type == T_QUEEN || type == T_BEETLE);
+        BB domain;
+        if (!own) domain = bb_not(bb_zero());
+        else if (adjacent_domain) domain = bb_neighbours(srcbit);
+        else domain = nmt;
+        if (turn <= 2u) {
+            BB base = bb_andn(type == T_BEETLE ? bb_not(bb_zero()) : bb_not(occ), srcbit);
+            D = bb_and(domain, base);
+            D = bb_and(D, turn == 1u ? bb_bit((unsigned)kStartCell) : nocc);
+        } else if (gate) {
+            D = bb_and(rule, domain);
+        }
+    }
+    out.D = D;
+    out.cell = on_board ? c : kHand;
+    out.lvl = lv;
+    out.h = h;
+    out.on_board = on_board;
+    out.on_top = on_top;
+    out.pinned = pinned;
+    return out;
+}
+
+// value encoders for the plane writer
+template <typename T> struct PlaneVal;
+template <> struct PlaneVal<float> {
+    static __device__ __forceinline__ uint32_t one() { return 0x3F800000u; }
+    static __device__ __forceinline__ uint32_t of(unsigned v) { return __float_as_uint((float)v); }
+};
+struct half_tag {};
+struct bf16_tag {};
+template <> struct PlaneVal<half_tag> {
+    static __device__ __forceinline__ uint32_t one() { return 0x3C00u; }
+    static __device__ __forceinline__ uint32_t of(unsigned v)
+    {
+        _Float16 hval = (_Float16)(float)v;
+        return (uint32_t) __builtin_bit_cast(unsigned short, hval);
+    }
+};
+template <> struct PlaneVal<bf16_tag> {
+    static __device__ __forceinline__ uint32_t one() { return 0x3F80u; }
+    static __device__ __forceinline__ uint32_t of(unsigned v) { return __float_as_uint((float)v) >> 16; }   // v <= 255: exact
+};
+
+// FULL = false: movegen for the side to move.  FULL = true: both colours + the 56 planes.
+// DT: 0 f32, 1 f16, 2 bf16 (only used when FULL).
+template <bool FULL, int DT, int LAYOUT>
+__global__ void __launch_bounds__(NW * 64)
+hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restrict__ hist, int n,
+                unsigned long long *__restrict__ mask, int32_t *__restrict__ count, int16_t *__restrict__ list,
+                void *__restrict__ planes)
+{
+    __shared__ Smem<FULL> sm;
+    constexpr int G = Smem<FULL>::G;
+    constexpr bool ENC = FULL;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int bl = FULL ? (lane & 31) : lane;      // board of this lane inside the workgroup
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nthreads = NW * 64;
+    const long long gbase = (long long)blockIdx.x * G;
+
+    // ---------------- phase 0: stage records + LUTs, clear accumulators
+    for (int i = tid; i < G * 4; i += nthreads) {
+        int b = i >> 2, part = i & 3;
+        uint4 v;
+        if (gbase + b < n) v = reinterpret_cast<const uint4 *>(boards)[(gbase + b) * 4 + part];
+        else if (part == 0) v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        else if (part == 1) v = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, 0u);
+        else if (part == 2) v = make_uint4(0x00010100u, 0u, 0u, 0u);
+        else v = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint4 *>(sm.state[b])[part] = v;
+    }
+    for (int i = tid; i < G * 6; i += nthreads) {
+        (&sm.occ[0][0])[i] = 0u;
+        (&sm.topw[0][0])[i] = 0u;
+    }
+    for (int i = tid; i < kCells * 6; i += nthreads) (&sm.line[0][0])[i] = (&d_tables.line[0][0])[i];
+    for (int i = tid; i < kCells * 2; i += nthreads)
+        reinterpret_cast<uint32_t *>(&sm.nbr[0][0])[i] = reinterpret_cast<const uint32_t *>(&d_tables.nbr[0][0])[i];
+    if (ENC)
+        for (int i = tid; i < G * kCells; i += nthreads) (&sm.feat[0][0])[i] = 0ull;
+    __syncthreads();
+
+    // occupancy and top-colour boards: every (board, piece) pair ORs its bit in
+    for (int pi = tid; pi < G * 22; pi += nthreads) {
+        int b = pi % G, q = pi / G;
+        const uint32_t *st = sm.state[b];
+        unsigned c = state_byte(st, (unsigned)q);
+        if (c < (unsigned)kCells) {
+            unsigned lb = state_byte(st, 22u + ((unsigned)q >> 1));
+            unsigned lv = (q & 1) ? (lb >> 4) : (lb & 15u);
+            unsigned h = 0;
+            HIVE_UNROLL for (int r = 0; r < 22; ++r) h += (state_byte(st, (unsigned)r) == c) ? 1u : 0u;
+            unsigned wi, bit;
+            cell_word_bit(c, wi, bit);
+            atomicOr(&sm.occ[b][wi], 1u << bit);
+            if (lv + 1u == h && q < 11) atomicOr(&sm.topw[b][wi], 1u << bit);
+        }
+    }
+    __syncthreads();
+    if (tid < G) lds_store_bb(sm.nocc[tid], bb_neighbours(lds_bb(sm.occ[tid])));
+    __syncthreads();
+
+    // ---------------- phase 1: one lane per (board, piece), one piece slot per wave
+    const bool valid = gbase + bl < n;
+    const uint32_t *st = sm.state[bl];
+    const unsigned turn = state_byte(st, 33);
+    const int stm = (turn & 1u) ? 0 : 1;
+    const int type = slot_type(wv);
+    int q, di;
+    bool own;
+    if (!FULL) { q = stm * 11 + wv; di = wv; own = true; }
+    else { int col = lane >> 5; q = col * 11 + wv; di = q; own = (col == stm); }
+    PieceInfo pc = piece_dests(st, sm.occ[bl], sm.topw[bl], sm.nocc[bl], sm.line, q, type, own, valid);
+    lds_store_bb(sm.dest[di][bl], pc.D);
+
+    if (ENC) {
+        // ---------------- planes: per-piece feature bits (env_hive.py:352-429)
+        const int color = q >= 11 ? 1 : 0, slot = q - 11 * color;
+        if (pc.on_board) {
+            unsigned long long bits = 0ull;
+            const unsigned base_own = own ? 0u : 12u;
+            bits |= 1ull << (base_own + (unsigned)slot);
+            bits |= 1ull << (own ? 11u : 23u);
+            bits |= 1ull << 30;
+            if (type == T_BEETLE) {
+                const unsigned bb = own ? 24u : 27u;
+                if (pc.lvl == 2u) bits |= 1ull << bb;
+                if (pc.lvl == 3u) bits |= 1ull << (bb + 1u);
+                if (pc.lvl == 4u && pc.h == 5u) bits |= 1ull << (bb + 2u);
+            }
+            if (own) {
+                if (!pc.on_top || !bb_any(pc.D)) bits |= 1ull << 34;
+                unsigned eq = state_byte(st, (unsigned)((1 - stm) * 11));
+                if (pc.on_top && eq < (unsigned)kCells) {
+                    for (int i = 0; i < 6; ++i) {
+                        unsigned adj = sm.nbr[eq][i];
+                        if (!lds_test(sm.occ[bl], adj) && lds_test(sm.dest[di][bl], adj)) bits |= 1ull << (50 + i);
+                    }
+                }
+            } else {
+                if (!pc.on_top || pc.pinned) bits |= 1ull << 35;
+                unsigned oq = state_byte(st, (unsigned)(stm * 11));
+                if (pc.on_top && !pc.pinned && oq < (unsigned)kCells) {
+                    for (int i = 0; i < 6; ++i) {
+                        unsigned adj = sm.nbr[oq][i];
+                        if (!lds_test(sm.occ[bl], adj) && lds_test(sm.dest[di][bl], adj)) bits |= 1ull << (44 + i);
+                    }
+                }
+            }
+            atomicOr(&sm.feat[bl][pc.cell], bits);
+            if (type == T_QUEEN) {
+                const unsigned long long qb = 1ull << (own ? 32 : 33);
+                for (int i = 0; i < 6; ++i) {
+                    unsigned adj = sm.nbr[pc.cell][i];
+                    if (lds_test(sm.occ[bl], adj)) atomicOr(&sm.feat[bl][adj], qb);
+                }
+            }
+        }
+        // history planes 36..43 (env_hive.py:431-434): 64 boards x 8 boards-of-bits
+        if (tid < G * 8) {
+            int b = tid % G, hidx = tid / G;
+            if (gbase + b < n && hist != nullptr) {
+                const uint32_t *sb = sm.state[b];
+                unsigned t = state_byte(sb, 33), hl = state_byte(sb, 35);
+                int persp = (t & 1u) ? 0 : 1;
+                unsigned len = persp == 0 ? (hl & 15u) : (hl >> 4);
+                int age = hidx >> 1, k = hidx & 1;
+                if ((unsigned)age < len) {
+                    const uint32_t *src = hist[gbase + b].m[persp][age][k];
+                    const unsigned long long pb = 1ull << (36 + hidx);
+                    for (int w = 0; w < 6; ++w) {
+                        uint32_t word = src[w];
+                        while (word) {
+                            unsigned bit = __builtin_ctz(word);
+                            word &= word - 1u;
+                            unsigned cell = (2u * w + (bit >> 4)) * 12u + (bit & 15u);
+                            atomicOr(&sm.feat[b][cell], pb);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: 25 ballots per board -> 1584-bit mask, count, sorted id list
+    if (mask != nullptr || count != nullptr || list != nullptr) {
+        for (int b = wv; b < G; b += NW) {
+            if (gbase + b >= n) break;
+            const unsigned tb = state_byte(sm.state[b], 33);
+            const int qbase = FULL ? (((tb & 1u) ? 0 : 1) * 11) : 0;
+            unsigned long long mine = 0ull;
+            int total = 0;
+            for (int t = 0; t < 25; ++t) {
+                unsigned a = (unsigned)(t * 64 + lane);
+                unsigned cell = a / 11u, slot = a - cell * 11u;
+                bool pred = false;
+                if (a < (unsigned)HIVE_ACTIONS) pred = lds_test(sm.dest[qbase + slot][b], cell);
+                unsigned long long m = __ballot(pred);
+                if (lane == t) mine = m;
+                if (list != nullptr && pred) {
+                    int p = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (p < HIVE_LIST_CAP) list[(gbase + b) * HIVE_LIST_CAP + p] = (int16_t)a;
+                }
+                total += __popcll(m);
+            }
+            if (mask != nullptr && lane < 25) mask[(gbase + b) * 25 + lane] = mine;
+            if (count != nullptr && lane == 0) count[gbase + b] = total;
+            if (list != nullptr)
+                for (int p = total + lane; p < HIVE_LIST_CAP; p += 64) list[(gbase + b) * HIVE_LIST_CAP + p] = -1;
+        }
+    }
+
+    // ---------------- phase 3: expand the 56 feature bits per cell into the plane tensor
+    if (ENC && planes != nullptr) {
+        using V = typename std::conditional<DT == 0, float, typename std::conditional<DT == 1, half_tag, bf16_tag>::type>::type;
+        const uint32_t one = PlaneVal<V>::one();
+        constexpr int kItems = kCells * HIVE_PLANES / 8;    // 8 consecutive elements per item
+        for (int it = tid; it < G * kItems; it += nthreads) {
+            int b = it / kItems, e0 = (it - b * kItems) * 8;
+            if (gbase + b >= n) break;
+            const uint32_t tv = PlaneVal<V>::of(state_byte(sm.state[b], 33));
+            uint32_t v[8];
+            if (LAYOUT == HIVE_HWC) {
+                int cell = e0 / HIVE_PLANES, p0 = e0 - cell * HIVE_PLANES;
+                unsigned bits8 = (unsigned)(sm.feat[b][cell] >> p0) & 0xFFu;
+                HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = ((bits8 >> k) & 1u) ? one : 0u;
+                if (p0 == 24) v[7] = tv;      // plane 31 = raw turn number (env_hive.py:331)
+            } else {
+                int p = e0 / kCells, c0 = e0 - p * kCells;
+                HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = ((sm.feat[b][c0 + k] >> p) & 1ull) ? one : 0u;
+                if (p == 31) { HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = tv; }
+            }
+            const long long eoff = (gbase + b) * (long long)(kCells * HIVE_PLANES) + e0;
+            if (DT == 0) {
+                uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<float *>(planes) + eoff);
+                dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
+                dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
+            } else {
+                uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(planes) + eoff);
+                dst[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ step / reset / terminal
+__device__ __forceinline__ void set_cell_bit(uint32_t w[6], unsigned cell)
+{
+    unsigned wi, bit;
+    cell_word_bit(cell, wi, bit);
+    HIVE_UNROLL for (int i = 0; i < 6; ++i) w[i] |= (wi == (unsigned)i) ? (1u << bit) : 0u;
+}
+
+// GamePlay.move (env_hive.py:99-171); one lane per board.
+__global__ void hive_step_kernel(HiveBoard *__restrict__ boards, HiveHistory *__restrict__ hist, int n,
+                                 const int32_t *__restrict__ actions, const uint32_t *__restrict__ legal_mask,
+                                 unsigned long long *__restrict__ illegal_count)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    int a = actions[b];
+    if (a == -2) return;
+    HiveBoard *B = &boards[b];
+    unsigned turn = B->turn, flags = B->flags, hl = B->hist_len;
+    const int stm = (turn & 1u) ? 0 : 1;
+    if (a < -2 || a >= HIVE_ACTIONS) { atomicAdd(illegal_count, 1ull); return; }
+    if (a >= 0 && legal_mask != nullptr) {
+        uint32_t wmask = legal_mask[(long long)b * HIVE_MASK_WORDS + (a >> 5)];
+        if (!((wmask >> (a & 31)) & 1u)) { atomicAdd(illegal_count, 1ull); return; }
+    }
+    // the planes of the position we are leaving inserted it into its perspective's history
+    // (env_hive.py:436-445); apply that insertion now, before the board changes
+    if ((flags & 4u) && hist != nullptr) {
+        uint32_t ownm[6] = {0, 0, 0, 0, 0, 0}, enm[6] = {0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < 22; ++r) {
+            unsigned c = B->pos[r];
+            if (c < (unsigned)kCells) {
+                if ((r >= 11 ? 1 : 0) == stm) set_cell_bit(ownm, c);
+                else set_cell_bit(enm, c);
+            }
+        }
+        HiveHistory *H = &hist[b];
+        for (int age = 3; age > 0; --age)
+            for (int k = 0; k < 2; ++k)
+                for (int w = 0; w < 6; ++w) H->m[stm][age][k][w] = H->m[stm][age - 1][k][w];
+        for (int w = 0; w < 6; ++w) { H->m[stm][0][0][w] = ownm[w]; H->m[stm][0][1][w] = enm[w]; }
+        unsigned len = stm == 0 ? (hl & 15u) : (hl >> 4);
+        len = len < 4u ? len + 1u : 4u;
+        hl = stm == 0 ? ((hl & 0xF0u) | len) : ((hl & 0x0Fu) | (len << 4));
+    }
+    if (a == -1) {
+        // pass (env_hive.py:100-103) and skip_turn (:493-496): next_move_tiles are not rebuilt
+        B->turn = (uint8_t)(turn + 1u);
+        B->flags = (uint8_t)(flags & 3u);
+        B->hist_len = (uint8_t)hl;
+        return;
+    }
+    const unsigned cell = (unsigned)a / 11u, slot = (unsigned)a - cell * 11u;
+    const unsigned q = (unsigned)stm * 11u + slot;
+    unsigned h = 0;
+    for (int r = 0; r < 22; ++r) h += (B->pos[r] == cell && (unsigned)r != q) ? 1u : 0u;   // len(end_tile.pieces), :119,125
+    B->pos[q] = (uint8_t)cell;
+    uint8_t lb = B->lvl[q >> 1];
+    B->lvl[q >> 1] = (q & 1u) ? (uint8_t)((lb & 0x0Fu) | (h << 4)) : (uint8_t)((lb & 0xF0u) | h);
+    turn += 1u;
+    B->turn = (uint8_t)turn;
+    B->flags = (uint8_t)((turn == 2u ? 2u : 0u) | 4u);
+    B->hist_len = (uint8_t)hl;
+}
+
+__global__ void hive_reset_kernel(HiveBoard *__restrict__ boards, HiveHistory *__restrict__ hist, int n,
+                                  const int32_t *__restrict__ idx, int k)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    int b = idx ? idx[i] : i;
+    if (b < 0 || b >= n) return;
+    uint4 *p = reinterpret_cast<uint4 *>(&boards[b]);
+    p[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    p[1] = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, 0u);
+    p[2] = make_uint4(0x00050100u, 0u, 0u, 0u);     // lvl[10]=0, turn=1, flags = nmt_mode 1 | history bit, hist_len=0
+    p[3] = make_uint4(0u, 0u, 0u, 0u);
+    if (hist) {
+        uint4 *hp = reinterpret_cast<uint4 *>(&hist[b]);
+        for (int j = 0; j < (int)(sizeof(HiveHistory) / 16); ++j) hp[j] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+// move_checker.py:140-165
+__global__ void hive_terminal_kernel(const HiveBoard *__restrict__ boards, int n, int8_t *__restrict__ over,
+                                     int8_t *__restrict__ winner)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    const HiveBoard *B = &boards[b];
+    bool surrounded[2] = {false, false};
+    for (int col = 0; col < 2; ++col) {
+        unsigned c = B->pos[col * 11];
+        if (c >= (unsigned)kCells) continue;
+        int cnt = 0;
+        for (int i = 0; i < 6; ++i) {
+            unsigned adj = d_tables.nbr[c][i];
+            bool occd = false;
+            for (int r = 0; r < 22; ++r) occd = occd || (B->pos[r] == adj);
+            cnt += occd ? 1 : 0;
+        }
+        surrounded[col] = cnt == 6;
+    }
+    bool ov = surrounded[0] || surrounded[1];
+    int w = 0;
+    if (surrounded[0] && !surrounded[1]) w = 2;       // white queen surrounded -> black wins
+    else if (surrounded[1] && !surrounded[0]) w = 1;
+    if (over) over[b] = ov ? 1 : 0;
+    if (winner) winner[b] = (int8_t)w;
+}
+
+// debug/test hook: copy the compile-time tables out (tests/test_tables.py)
+__global__ void hive_tables_kernel(uint32_t *line, uint8_t *nbr)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < kCells * 6) line[i] = (&d_tables.line[0][0])[i];
+    if (i < kCells * 8) nbr[i] = (&d_tables.nbr[0][0])[i];
+}
+
+}  // namespace hive
+
+// ====================================================================== host side / C ABI
+using namespace hive;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(HIVE_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+struct HiveBatch {
+    int n = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    HiveBoard *boards = nullptr;
+    HiveHistory *hist = nullptr;
+    uint32_t *legal = nullptr;              // cached legal mask of the current positions
+    int32_t *legal_count = nullptr;
+    int16_t *legal_list = nullptr;
+    bool legal_valid = false;
+    unsigned long long *illegal = nullptr;  // device counter
+};
+
+extern "C" {
+
+const char *hive_last_error(void) { return g_err.c_str(); }
+const char *hive_version(void) { return "hive-hip 0.1 (gfx950)"; }
+
+int hive_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return c;
+}
+
+static int launch_env(const HiveBoard *boards, const HiveHistory *hist, int n, uint32_t *mask, int32_t *count,
+                      int16_t *list, void *planes, int dtype, int layout, hipStream_t stream)
+{
+    if (n <= 0 || boards == nullptr) return fail(HIVE_E_ARG, "launch_env: n <= 0 or boards == NULL");
+    unsigned long long *m64 = reinterpret_cast<unsigned long long *>(mask);
+    if (planes == nullptr) {
+        dim3 grid((unsigned)((n + 63) / 64));
+        hipLaunchKernelGGL((hive_env_kernel<false, 0, 0>), grid, dim3(NW * 64), 0, stream, boards, hist, n, m64,
+                           count, list, nullptr);
+    } else {
+        dim3 grid((unsigned)((n + 31) / 32));
+#define HIVE_ENC_CASE(DT, LY)                                                                              \
+    if (dtype == DT && layout == LY)                                                                       \
+        hipLaunchKernelGGL((hive_env_kernel<true, DT, LY>), grid, dim3(NW * 64), 0, stream, boards, hist, n, \
+                           m64, count, list, planes);
+        if (dtype < 0 || dtype > 2 || layout < 0 || layout > 1) return fail(HIVE_E_ARG, "unknown dtype/layout");
+        HIVE_ENC_CASE(0, 0) HIVE_ENC_CASE(0, 1) HIVE_ENC_CASE(1, 0) HIVE_ENC_CASE(1, 1) HIVE_ENC_CASE(2, 0)
+        HIVE_ENC_CASE(2, 1)
+#undef HIVE_ENC_CASE
+    }
+    HIP_TRY(hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_movegen_launch(const HiveBoard *boards, int n, uint32_t *mask, int32_t *count, int16_t *list, void *stream)
+{
+    return launch_env(boards, nullptr, n, mask, count, list, nullptr, 0, 0, (hipStream_t)stream);
+}
+
+int hive_encode_launch(const HiveBoard *boards, const HiveHistory *hist, int n, void *planes, HiveDType dtype,
+                       HiveLayout layout, void *stream)
+{
+    if (planes == nullptr) return fail(HIVE_E_ARG, "hive_encode_launch: planes == NULL");
+    return launch_env(boards, hist, n, nullptr, nullptr, nullptr, planes, (int)dtype, (int)layout, (hipStream_t)stream);
+}
+
+int hive_batch_create(int n, int device, HiveBatch **out)
+{
+    if (n <= 0 || out == nullptr) return fail(HIVE_E_ARG, "hive_batch_create: n <= 0 or out == NULL");
+    int cnt = hive_device_count();
+    if (cnt <= 0) return fail(HIVE_E_DEVICE, "hive_batch_create: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= cnt) return fail(HIVE_E_ARG, "hive_batch_create: bad device ordinal");
+    HIP_TRY(hipSetDevice(device));
+    HiveBatch *h = new HiveBatch();
+    h->n = n;
+    h->device = device;
+    HIP_TRY(hipMalloc(&h->boards, sizeof(HiveBoard) * (size_t)n));
+    HIP_TRY(hipMalloc(&h->hist, sizeof(HiveHistory) * (size_t)n));
+    HIP_TRY(hipMalloc(&h->legal, sizeof(uint32_t) * HIVE_MASK_WORDS * (size_t)n));
+    HIP_TRY(hipMalloc(&h->legal_count, sizeof(int32_t) * (size_t)n));
+    HIP_TRY(hipMalloc(&h->legal_list, sizeof(int16_t) * HIVE_LIST_CAP * (size_t)n));
+    HIP_TRY(hipMalloc(&h->illegal, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->illegal, 0, sizeof(unsigned long long)));
+    *out = h;
+    return hive_batch_reset(h, nullptr, n);
+}
+
+int hive_batch_destroy(HiveBatch *h)
+{
+    if (!h) return HIVE_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->boards);
+    (void)hipFree(h->hist);
+    (void)hipFree(h->legal);
+    (void)hipFree(h->legal_count);
+    (void)hipFree(h->legal_list);
+    (void)hipFree(h->illegal);
+    delete h;
+    return HIVE_OK;
+}
+
+int hive_batch_size(const HiveBatch *h) { return h ? h->n : 0; }
+
+int hive_batch_set_stream(HiveBatch *h, void *stream)
+{
+    if (!h) return fail(HIVE_E_ARG, "null handle");
+    h->stream = (hipStream_t)stream;
+    return HIVE_OK;
+}
+
+int hive_batch_reset(HiveBatch *h, const int32_t *idx, int k)
+{
+    if (!h) return fail(HIVE_E_ARG, "null handle");
+    if (idx == nullptr) k = h->n;
+    if (k <= 0) return HIVE_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(hive_reset_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, h->stream, h->boards,
+                       h->hist, h->n, idx, k);
+    HIP_TRY(hipGetLastError());
+    h->legal_valid = false;
+    return HIVE_OK;
+}
+
+static int ensure_legal(HiveBatch *h)
+{
+    if (h->legal_valid) return HIVE_OK;
+    int rc = launch_env(h->boards, nullptr, h->n, h->legal, h->legal_count, h->legal_list, nullptr, 0, 0, h->stream);
+    if (rc == HIVE_OK) h->legal_valid = true;
+    return rc;
+}
+
+int hive_batch_legal(HiveBatch *h, uint32_t *mask, int32_t *count, int16_t *list)
+{
+    if (!h) return fail(HIVE_E_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = ensure_legal(h);
+    if (rc != HIVE_OK) return rc;
+    size_t n = (size_t)h->n;
+    if (mask) HIP_TRY(hipMemcpyAsync(mask, h->legal, sizeof(uint32_t) * HIVE_MASK_WORDS * n, hipMemcpyDeviceToDevice, h->stream));
+    if (count) HIP_TRY(hipMemcpyAsync(count, h->legal_count, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, h->stream));
+    if (list) HIP_TRY(hipMemcpyAsync(list, h->legal_list, sizeof(int16_t) * HIVE_LIST_CAP * n, hipMemcpyDeviceToDevice, h->stream));
+    return HIVE_OK;
+}
+
+int hive_batch_illegal_count(HiveBatch *h, int64_t *count)
+{
+    if (!h || !count) return fail(HIVE_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, h->illegal, sizeof v, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *count = (int64_t)v;
+    return HIVE_OK;
+}
+
+int hive_batch_step(HiveBatch *h, const int32_t *actions, int sync)
+{
+    if (!h || !actions) return fail(HIVE_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = ensure_legal(h);
+    if (rc != HIVE_OK) return rc;
+    int64_t before = 0;
+    if (sync) { rc = hive_batch_illegal_count(h, &before); if (rc != HIVE_OK) return rc; }
+    hipLaunchKernelGGL(hive_step_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->boards,
+                       h->hist, h->n, actions, h->legal, h->illegal);
+    HIP_TRY(hipGetLastError());
+    h->legal_valid = false;
+    if (sync) {
+        int64_t after = 0;
+        rc = hive_batch_illegal_count(h, &after);
+        if (rc != HIVE_OK) return rc;
+        if (after != before) {
+            char buf[96];
+            snprintf(buf, sizeof buf, "hive_batch_step: %lld board(s) refused an illegal action", (long long)(after - before));
+            return fail(HIVE_E_ILLEGAL, buf);
+        }
+    }
+    return HIVE_OK;
+}
+
+int hive_batch_encode(HiveBatch *h, void *planes, HiveDType dtype, HiveLayout layout)
+{
+    if (!h || !planes) return fail(HIVE_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    return launch_env(h->boards, h->hist, h->n, nullptr, nullptr, nullptr, planes, (int)dtype, (int)layout, h->stream);
+}
+
+int hive_batch_terminal(HiveBatch *h, int8_t *over, int8_t *winner)
+{
+    if (!h) return fail(HIVE_E_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(hive_terminal_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->boards,
+                       h->n, over, winner);
+    HIP_TRY(hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_batch_export(HiveBatch *h, HiveBoard *boards, HiveHistory *hist)
+{
+    if (!h) return fail(HIVE_E_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    if (boards) HIP_TRY(hipMemcpyAsync(boards, h->boards, sizeof(HiveBoard) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+    if (hist) HIP_TRY(hipMemcpyAsync(hist, h->hist, sizeof(HiveHistory) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+    return HIVE_OK;
+}
+
+int hive_batch_import(HiveBatch *h, const HiveBoard *boards, const HiveHistory *hist)
+{
+    if (!h || !boards) return fail(HIVE_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->boards, boards, sizeof(HiveBoard) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+    if (hist) HIP_TRY(hipMemcpyAsync(h->hist, hist, sizeof(HiveHistory) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+    else HIP_TRY(hipMemsetAsync(h->hist, 0, sizeof(HiveHistory) * (size_t)h->n, h->stream));
+    h->legal_valid = false;
+    return HIVE_OK;
+}
+
+// test hook (not in hive_abi.h's product surface): copy the device tables to device buffers
+int hive_debug_tables(uint32_t *line /* [144*6] */, uint8_t *nbr /* [144*8] */, void *stream)
+{
+    hipLaunchKernelGGL(hive_tables_kernel, dim3(5), dim3(256), 0, (hipStream_t)stream, line, nbr);
+    HIP_TRY(hipGetLastError());
+    return HIVE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+/*
+ * hive_abi.h -- C ABI of libhive_hip.so, the MI355X (gfx950) Hive env engine.
+ *
+ * The reference (HaiDangDang/hive-Alphazero) is pure Python and has no FFI layer; its
+ * boundary is the duck-typed GamePlay object (hive_engine/env_hive.py:24-507).  Each
+ * entry point below names the reference interface it replaces (paths relative to the
+ * reference root).  The Python mirror of GamePlay that a reference caller
+ * (woker/self_play.py, woker/solo_play.py, alpha_zero/MCTS_chess.py) imports instead is
+ * hive-alphazero_amd/env_hive.py; INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - cell   = index_xy[0]*12 + index_xy[1]               (tile.py:190-196)
+ *   - piece  = colour*11 + slot; colour 0 = white; slot order Q,B,B,S,S,G,G,G,A,A,A
+ *              (inventory_frame.py:47-99, env_hive.py:66-87)
+ *   - action = cell*11 + slot, pass = -1                   (env_hive.py:100-114,287-304)
+ *   - All array arguments are DEVICE pointers (HBM) unless a parameter says "host".
+ *     The caller allocates every output buffer; the library owns only the handle.
+ *   - Every call returns 0 on success or a negative HIVE_E_* code; hive_last_error()
+ *     gives the message for the calling thread.  Nothing throws across the ABI.
+ *   - A handle is not thread-safe; distinct handles are independent.  All work of a
+ *     handle is enqueued on its HIP stream (hive_batch_set_stream); calls are
+ *     asynchronous unless stated otherwise.
+ *   - Positions must be reachable by legal play (connected hive); the one-hive test
+ *     relies on that exactly like the reference's BFS does.
+ */
+#ifndef HIVE_ABI_H
+#define HIVE_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIVE_CELLS 144
+#define HIVE_PIECES 22
+#define HIVE_ACTIONS 1584          /* hive_engine/config.py:10 ACTION_SPACE */
+#define HIVE_PLANES 56             /* hive_engine/config.py:20 STATE_FEATURES */
+#define HIVE_MASK_WORDS 50         /* 1584 bits padded to 25 x u64 = 50 x u32 */
+#define HIVE_IN_HAND 255
+#define HIVE_LIST_CAP 256          /* capacity of one compacted legal-id row */
+
+enum {
+    HIVE_OK = 0,
+    HIVE_E_ARG = -1,        /* bad argument (null pointer, n <= 0, unknown enum) */
+    HIVE_E_DEVICE = -2,     /* HIP runtime error (no device, launch failure, OOM) */
+    HIVE_E_ILLEGAL = -3,    /* at least one action was not in the legal set; those boards are unchanged */
+    HIVE_E_STATE = -4       /* imported position is malformed */
+};
+
+/* One board in HBM: 64 bytes, 16-byte aligned.  Replaces the GamePlay object graph
+ * (env_hive.py:26-57: white/black_pieces_set, state.turn, next_move_tiles). */
+typedef struct HiveBoard {
+    uint8_t pos[HIVE_PIECES];   /* cell of each piece, HIVE_IN_HAND if not placed */
+    uint8_t lvl[11];            /* 4-bit stack index per piece: piece 2k = low nibble of lvl[k] */
+    uint8_t turn;               /* game_state.py:38, starts at 1 */
+    uint8_t flags;              /* bits 0-1 nmt_mode (0 rebuilt from occupancy, 1 start tile only,
+                                   2 turn-2 tile only: env_hive.py:66-69,150-161);
+                                   bit 2: the encode of this position inserts it into the
+                                   history (env_hive.py:51,146,436-445) */
+    uint8_t hist_len;           /* low nibble: entries visible to white's planes, high: black's */
+    uint8_t rsv[28];
+} HiveBoard;
+
+/* History bit-planes of one board: [perspective][age, 0 = newest][0 = own, 1 = enemy][6 words].
+ * Word r holds board rows 2r (bits 0-11) and 2r+1 (bits 16-27).  384 bytes.
+ * Replaces GamePlay.history_white / history_black (env_hive.py:38-39,431-445). */
+typedef struct HiveHistory {
+    uint32_t m[2][4][2][6];
+} HiveHistory;
+
+typedef enum { HIVE_F32 = 0, HIVE_F16 = 1, HIVE_BF16 = 2 } HiveDType;
+typedef enum {
+    HIVE_HWC = 0,   /* [n][12][12][56], the reference's encode_board layout (channels-last) */
+    HIVE_CHW = 1    /* [n][56][12][12], what api_hive.py:60 builds with transpose(2,0,1) */
+} HiveLayout;
+
+typedef struct HiveBatch HiveBatch;
+
+const char *hive_last_error(void);
+const char *hive_version(void);
+
+/* Number of visible HIP devices (0 when none); never fails. */
+int hive_device_count(void);
+
+/* GamePlay.__init__/new_game for n boards (env_hive.py:26-97).  device = HIP ordinal. */
+int hive_batch_create(int n, int device, HiveBatch **out);
+int hive_batch_destroy(HiveBatch *h);
+int hive_batch_size(const HiveBatch *h);
+/* stream = hipStream_t (NULL = default stream). */
+int hive_batch_set_stream(HiveBatch *h, void *stream);
+
+/* GamePlay.new_game (env_hive.py:61-97) for the boards listed in idx (device int32[k]);
+ * idx == NULL resets all n boards. */
+int hive_batch_reset(HiveBatch *h, const int32_t *idx, int k);
+
+/* GamePlay.move (env_hive.py:99-171) for every board: actions = device int32[n], -1 = pass
+ * (also GamePlay.skip_turn, env_hive.py:493-496), -2 = leave this board untouched.
+ * The reference applies illegal actions blindly (its assert is commented out,
+ * env_hive.py:129-144); here a board whose action is not legal is left unchanged and
+ * counted.  With sync != 0 the call waits and returns HIVE_E_ILLEGAL if any board
+ * refused; with sync == 0 read the running total with hive_batch_illegal_count. */
+int hive_batch_step(HiveBatch *h, const int32_t *actions, int sync);
+int hive_batch_illegal_count(HiveBatch *h, int64_t *count /* host */);
+
+/* GamePlay.actions (env_hive.py:182-183, 196-304): legal set of the side to move.
+ * mask  = device uint32[n][HIVE_MASK_WORDS], bit a = action a legal (may be NULL);
+ * count = device int32[n] (may be NULL);
+ * list  = device int16[n][HIVE_LIST_CAP], ascending action ids, -1 padded (may be NULL);
+ *         a board with more than HIVE_LIST_CAP legal ids keeps the first HIVE_LIST_CAP. */
+int hive_batch_legal(HiveBatch *h, uint32_t *mask, int32_t *count, int16_t *list);
+
+/* GamePlay.encode_board (env_hive.py:306-485): the 56 planes from the mover's side. */
+int hive_batch_encode(HiveBatch *h, void *planes, HiveDType dtype, HiveLayout layout);
+
+/* GamePlay.game_is_over (move_checker.py:140-165): over[n] int8 0/1,
+ * winner[n] int8 0 none / 1 white / 2 black. */
+int hive_batch_terminal(HiveBatch *h, int8_t *over, int8_t *winner);
+
+/* Raw state exchange (deepcopy(env) in solo_play.py:158 / MCTS_chess.py:104):
+ * boards = device HiveBoard[n], hist = device HiveHistory[n] (hist may be NULL). */
+int hive_batch_export(HiveBatch *h, HiveBoard *boards, HiveHistory *hist);
+int hive_batch_import(HiveBatch *h, const HiveBoard *boards, const HiveHistory *hist);
+
+/* Stateless launches over caller-owned state arrays (used by the tree search, where
+ * positions live in node pools).  Same semantics as the batch calls above. */
+int hive_movegen_launch(const HiveBoard *boards, int n, uint32_t *mask, int32_t *count,
+                        int16_t *list, void *stream);
+int hive_encode_launch(const HiveBoard *boards, const HiveHistory *hist, int n, void *planes,
+                       HiveDType dtype, HiveLayout layout, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIVE_ABI_H */

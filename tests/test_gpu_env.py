@@ -1,0 +1,255 @@
+"""GPU parity tests: the HIP env kernels (through the C ABI) against the golden vectors of
+the true reference and against the CPU oracle on seeded random playouts.  Bit-exact."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test run without a visible GPU")
+
+
+@pytest.fixture(scope="module")
+def hv():
+    _need_gpu()
+    import hive_alphazero_amd as h
+    from hive_alphazero_amd import batch, packing
+    h.load()
+    return h, batch, packing
+
+
+def _mask_rows_to_lists(mask):
+    m = mask.cpu().numpy().view(np.uint32)
+    bits = np.unpackbits(m.view(np.uint8).reshape(m.shape[0], -1), axis=1, bitorder="little")[:, :1584]
+    return [np.nonzero(r)[0].tolist() for r in bits]
+
+
+def _mode_of(rec):
+    return 1 if rec["t"] == 1 else (2 if rec["t"] == 2 else 0)
+
+
+def test_device_tables(hv, golden_tables):
+    h, batch, packing = hv
+    import ctypes
+    L = h.load()
+    line = torch.zeros(144 * 6, dtype=torch.int32, device="cuda")
+    nbr = torch.zeros(144 * 8, dtype=torch.uint8, device="cuda")
+    assert L.hive_debug_tables(ctypes.c_void_p(line.data_ptr()), ctypes.c_void_p(nbr.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    line = line.cpu().numpy().view(np.uint32).reshape(144, 6)
+    nbr = nbr.cpu().numpy().reshape(144, 8)
+    for a in range(144):
+        assert packing.words_to_cells(line[a]) == golden_tables["line"][a]
+        assert nbr[a, :6].tolist() == golden_tables["nbr"][a]
+
+
+def _golden_positions(games):
+    recs = [rec for gm in games for rec in gm["plies"]]
+    turn = np.array([r["t"] for r in recs])
+    pos = np.array([r["pos"] for r in recs], dtype=np.uint8)
+    lvl = np.array([r["lvl"] for r in recs], dtype=np.uint8)
+    mode = np.array([_mode_of(r) for r in recs], dtype=np.uint8)
+    return recs, turn, pos, lvl, mode
+
+
+def test_movegen_golden_positions(hv, golden_games):
+    """Config C2 shape: a flat batch of positions -> legal mask/count/list, bit-exact vs the reference."""
+    h, batch, packing = hv
+    recs, turn, pos, lvl, mode = _golden_positions(golden_games)
+    boards = torch.from_numpy(packing.pack_boards(turn, pos, lvl, mode)).cuda()
+    mask, count, lst = batch.movegen(boards, want_list=True)
+    torch.cuda.synchronize()
+    got = _mask_rows_to_lists(mask)
+    cnt = count.cpu().numpy()
+    lst = lst.cpu().numpy()
+    bad = 0
+    for i, r in enumerate(recs):
+        if got[i] != r["legal"]:
+            bad += 1
+            if bad < 5:
+                print("mismatch at", i, "turn", r["t"], "extra", sorted(set(got[i]) - set(r["legal"])),
+                      "missing", sorted(set(r["legal"]) - set(got[i])))
+        assert cnt[i] == len(r["legal"])
+        assert lst[i, :cnt[i]].tolist() == r["legal"]
+        assert np.all(lst[i, cnt[i]:] == -1)
+    assert bad == 0, f"{bad} of {len(recs)} positions differ"
+
+
+def test_movegen_golden_movegen_set(hv):
+    path = os.path.join(GOLD, "games_movegen.json.gz")
+    if not os.path.exists(path):
+        pytest.skip("games_movegen.json.gz not generated")
+    h, batch, packing = hv
+    with gzip.open(path, "rt") as f:
+        games = json.load(f)["games"]
+    recs, turn, pos, lvl, mode = _golden_positions(games)
+    boards = torch.from_numpy(packing.pack_boards(turn, pos, lvl, mode)).cuda()
+    mask, count, _ = batch.movegen(boards)
+    got = _mask_rows_to_lists(mask)
+    bad = sum(1 for i, r in enumerate(recs) if got[i] != r["legal"])
+    assert bad == 0, f"{bad} of {len(recs)} positions differ"
+
+
+def test_replay_golden_games(hv, golden_games):
+    """step + movegen + encode + terminal + history, ply by ply, against the reference's games."""
+    h, batch, packing = hv
+    games = golden_games
+    n = len(games)
+    B = batch.BoardBatch(n)
+    maxlen = max(len(g["plies"]) for g in games)
+    for ply in range(maxlen):
+        mask, count, _ = B.legal()
+        planes = B.encode(torch.float32, "hwc")
+        over, winner = B.terminal()
+        boards, _ = B.export_state()
+        torch.cuda.synchronize()
+        got = _mask_rows_to_lists(mask)
+        planes = planes.cpu().numpy()
+        over = over.cpu().numpy()
+        winner = winner.cpu().numpy()
+        st = packing.unpack_boards(boards.cpu().numpy())
+        acts = np.full(n, -2, dtype=np.int32)
+        for gi, gm in enumerate(games):
+            if ply >= len(gm["plies"]):
+                continue
+            rec = gm["plies"][ply]
+            ctx = f"seed {gm['seed']} ply {ply}"
+            assert st["turn"][gi] == rec["t"], ctx
+            assert st["pos"][gi].tolist() == rec["pos"], ctx
+            assert [int(l) if p != 255 else 0 for p, l in zip(st["pos"][gi], st["lvl"][gi])] == rec["lvl"], ctx
+            assert got[gi] == rec["legal"], ctx
+            assert bool(over[gi]) == rec["over"], ctx
+            if rec["over"]:
+                assert int(winner[gi]) == rec["win"], ctx
+            pl = planes[gi]
+            assert np.all(pl[:, :, 31] == rec["t"]), ctx
+            pl = pl.copy()
+            pl[:, :, 31] = 0
+            nz = np.argwhere(pl != 0)
+            assert np.all(pl[pl != 0] == 1), ctx
+            gotp = sorted(int((x * 12 + y) * 56 + p) for x, y, p in nz)
+            if gotp != rec["planes"]:
+                diff = sorted(set(gotp) ^ set(rec["planes"]))
+                raise AssertionError(f"{ctx}: planes differ at (cell,plane) {[(d // 56, d % 56) for d in diff]}")
+            if rec["a"] is not None:
+                acts[gi] = rec["a"]
+        B.step(acts, sync=True)
+    B.close()
+
+
+def test_encode_variants_agree(hv, golden_games):
+    h, batch, packing = hv
+    games = golden_games[:16]
+    B = batch.BoardBatch(len(games))
+    for ply in range(12):
+        acts = np.array([g["plies"][ply]["a"] for g in games], dtype=np.int32)
+        B.step(acts)
+    ref = B.encode(torch.float32, "hwc").cpu()
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        hwc = B.encode(dt, "hwc").float().cpu()
+        chw = B.encode(dt, "chw").float().cpu()
+        assert torch.equal(hwc, ref)
+        assert torch.equal(chw, ref.permute(0, 3, 1, 2))
+    B.close()
+
+
+def test_illegal_action_is_refused(hv):
+    h, batch, packing = hv
+    from hive_alphazero_amd import HiveError
+    B = batch.BoardBatch(3)
+    before, _ = B.export_state()
+    with pytest.raises(HiveError) as ei:
+        B.step(np.array([858, 0, 859], dtype=np.int32))     # board 1: cell 0 is not the start tile
+    assert ei.value.code == -3
+    after, _ = B.export_state()
+    st0, st1 = packing.unpack_boards(before.cpu().numpy()), packing.unpack_boards(after.cpu().numpy())
+    assert st1["turn"].tolist() == [2, 1, 2]
+    assert st1["pos"][1].tolist() == st0["pos"][1].tolist()
+    assert B.illegal_count() == 1
+    B.close()
+
+
+def _oracle_corpus(n, seed):
+    """n positions sampled from oracle random playouts (seeded)."""
+    from oracle import oracle_py as O
+    rng = np.random.default_rng(seed)
+    turn, pos, lvl, mode, legal = [], [], [], [], []
+    while len(turn) < n:
+        g = O.OracleGame()
+        while True:
+            acts = g.actions()
+            p, l = g.pieces()
+            turn.append(g.turn); pos.append(p); lvl.append(l); mode.append(g.nmt_mode); legal.append(acts)
+            over, _ = g.game_is_over()
+            if over or g.turn >= 55 or len(turn) >= n:
+                break
+            g.move(int(acts[rng.integers(len(acts))]) if acts else -1)
+    return np.array(turn), np.array(pos), np.array(lvl), np.array(mode, dtype=np.uint8), legal
+
+
+def test_movegen_4096_vs_oracle(hv):
+    """BASELINE config 2 at full size: 4096 boards, bit-exact against the CPU oracle."""
+    h, batch, packing = hv
+    turn, pos, lvl, mode, legal = _oracle_corpus(4096, seed=1234)
+    boards = torch.from_numpy(packing.pack_boards(turn, pos, lvl, mode)).cuda()
+    mask, count, lst = batch.movegen(boards, want_list=True)
+    got = _mask_rows_to_lists(mask)
+    assert got == legal
+    assert count.cpu().numpy().tolist() == [len(x) for x in legal]
+    # size-independent properties: the list is sorted, strictly increasing and agrees with the mask
+    lst = lst.cpu().numpy()
+    for i in range(0, 4096, 97):
+        k = len(legal[i])
+        assert lst[i, :k].tolist() == legal[i]
+    # ragged batch sizes (tail workgroup handling)
+    for n in (1, 63, 65, 127):
+        m2, c2, _ = batch.movegen(boards[:n].contiguous())
+        assert _mask_rows_to_lists(m2) == legal[:n]
+
+
+def test_random_playout_vs_oracle_lockstep(hv):
+    """256 games stepped on the GPU and in the oracle with the same actions; every ply compared
+    (legal sets, planes, terminal flags), including passes and finished games."""
+    h, batch, packing = hv
+    from oracle import oracle_py as O
+    n = 256
+    rng = np.random.default_rng(7)
+    B = batch.BoardBatch(n)
+    games = [O.OracleGame() for _ in range(n)]
+    done = np.zeros(n, dtype=bool)
+    for ply in range(56):
+        mask, count, _ = B.legal()
+        planes = B.encode(torch.bfloat16, "hwc").float().cpu().numpy()
+        over, winner = B.terminal()
+        got = _mask_rows_to_lists(mask)
+        over = over.cpu().numpy(); winner = winner.cpu().numpy()
+        acts = np.full(n, -2, dtype=np.int32)
+        for i, g in enumerate(games):
+            if done[i]:
+                continue
+            want = g.actions()
+            assert got[i] == want, (i, ply)
+            o, w = g.game_is_over()
+            assert bool(over[i]) == o and (not o or int(winner[i]) == w), (i, ply)
+            assert np.array_equal(planes[i], g.encode_board()), (i, ply)
+            if o or g.turn >= 55:
+                done[i] = True
+                continue
+            a = int(want[rng.integers(len(want))]) if want else -1
+            acts[i] = a
+            g.move(a)
+        if done.all():
+            break
+        B.step(acts, sync=True)
+    assert done.all()
+    B.close()
