@@ -1,11 +1,12 @@
 // hive_env.hip -- batched Hive env kernels for gfx950 (MI355X) + the C ABI of include/hive_abi.h.
 //
-// Work decomposition: one workgroup owns G = 64 boards; wave w of the
-// workgroup owns piece slot w of all 64 boards, so every wave runs exactly one piece type
-// (no type divergence) and lane l of every wave works on board l.  The boards' packed
-// records, occupancy / top-colour bitboards and the is_straight_line LUT are staged in LDS;
-// per-piece destination bitboards go back to LDS and are turned into the 1584-bit legal mask
-// with 25 wave ballots per board (mbcnt prefix sums give the sorted id list).
+// Work decomposition: a (board, piece) pair is one DPP quad -- the 144-bit
+// boards are spread over three lanes (hive_bb.hpp) -- so a wavefront carries 16 pairs.  A
+// workgroup is 11 waves, wave w = piece slot w, hence every wave runs exactly one piece type
+// (no type divergence); it owns 16 boards (movegen) or 8 boards x both colours (planes).
+// The packed records and the occupancy / top-colour boards are staged in LDS; per-piece
+// destination boards go back to LDS and are turned into the 1584-bit legal mask with 25 wave
+// ballots per board (mbcnt prefix sums give the sorted id list).
 //
 // Reference semantics implemented here (paths relative to the reference root):
 //   env_hive.py:196-304   pre_actions / get_actions / encode_action
@@ -43,33 +44,23 @@ __device__ __forceinline__ int slot_group_start(int slot)
 }
 
 // ------------------------------------------------------------------ LDS image
-// FULL = false: G = 64 boards per workgroup, lane = board, wave = slot of the side to move.
-// FULL = true : G = 32 boards per workgroup, lanes 0-31 = white piece, lanes 32-63 = black piece
-//               of slot `wave` (both colours are needed by the planes); still one type per wave.
+// One workgroup = 11 waves (one per piece slot, so every wave runs a single piece type) x 16
+// quads.  FULL = false: 16 boards per workgroup, quad = board, wave = slot of the side to move.
+// FULL = true : 8 boards per workgroup, quads 0-7 = white piece, 8-15 = black piece of slot
+// `wave` (both colours are needed by the planes).
 template <bool FULL>
 struct Smem {
-    static constexpr int G = FULL ? 32 : 64;
+    static constexpr int G = FULL ? 8 : 16;
     static constexpr int ND = FULL ? 22 : 11;
+    static constexpr int DSTRIDE = G * 6 + 1;   // +1 word: the 11 slots of one cell land in 11 banks
     uint32_t state[G][16];       // HiveBoard records
     uint32_t occ[G][6];          // cells with at least one piece
     uint32_t topw[G][6];         // cells whose top piece is white
-    uint32_t nocc[G][6];         // neighbours(occ)
-    uint32_t line[kCells][6];    // is_straight_line LUT
-    uint8_t nbr[kCells][8];      // adjacent_tiles order LUT
-    uint32_t dest[ND][G][6];     // destination board of piece d on board g
+    uint32_t dest[ND][DSTRIDE];  // destination board of piece d on board g at [d][g*6 ..]
+    uint8_t nbr[FULL ? kCells : 1][8];                           // adjacent_tiles order LUT
     unsigned long long feat[FULL ? G : 1][FULL ? kCells : 1];   // 56 feature bits per cell
 };
 
-__device__ __forceinline__ BB lds_bb(const uint32_t *p)
-{
-    BB r;
-    HIVE_UNROLL for (int i = 0; i < 6; ++i) r.w[i] = p[i];
-    return r;
-}
-__device__ __forceinline__ void lds_store_bb(uint32_t *p, BB v)
-{
-    HIVE_UNROLL for (int i = 0; i < 6; ++i) p[i] = v.w[i];
-}
 __device__ __forceinline__ unsigned state_byte(const uint32_t *st, unsigned idx)
 {
     return reinterpret_cast<const uint8_t *>(st)[idx];
@@ -79,17 +70,6 @@ __device__ __forceinline__ bool lds_test(const uint32_t *bbp, unsigned cell)
     unsigned wi, bit;
     cell_word_bit(cell, wi, bit);
     return (bbp[wi] >> bit) & 1u;
-}
-
-// per-direction source boards -> union of the shifted boards (d0..d5 = R UR U L DL D)
-__device__ __forceinline__ BB shift_dirs(BB a0, BB a1, BB a2, BB a3, BB a4, BB a5)
-{
-    BB u2 = bb_up(a2), d5 = bb_down(a5);
-    BB r = bb_right(bb_or(a0, bb_up(a1)));
-    BB l = bb_left(bb_or(a3, bb_down(a4)));
-    BB o;
-    HIVE_UNROLL for (int i = 0; i < 6; ++i) o.w[i] = u2.w[i] | d5.w[i] | r.w[i] | l.w[i];
-    return o;
 }
 
 // move_checker.py:106-137
@@ -110,12 +90,12 @@ struct PieceInfo {
     bool on_board, on_top, pinned;
 };
 
-// Everything one (board, piece) lane computes.  `type` and the loops' trip tests are wave-uniform.
+// Everything one (board, piece) quad computes; scalars are replicated over the quad's lanes.
+// `type` and the loops' trip tests are wave-uniform.
 // own == true : get_actions semantics (env_hive.py:207-285)
 // own == false: mini_black_actions semantics for an enemy piece (env_hive.py:449-485)
 __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint32_t *occ_p, const uint32_t *topw_p,
-                                                 const uint32_t *nocc_p, const uint32_t (*line)[6], int q,
-                                                 int type, bool own, bool valid)
+                                                 int q, int type, bool own, bool valid)
 {
     PieceInfo out;
     const unsigned turn = state_byte(st, 33);
@@ -142,15 +122,18 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     const int first_color = wq ? 0 : 1;
     const bool stm_queen = stm == 0 ? wq : bq;
 
-    const BB occ = lds_bb(occ_p), nocc = lds_bb(nocc_p);
+    const BB occ = bb_load(occ_p);
+    const BB nocc = bb_neighbours(occ);
     const BB srcbit = bb_bit(on_board ? c : 255u);
     const BB occp = (on_board && !stacked) ? bb_xor(occ, srcbit) : occ;
+    const BB nsrc = bb_neighbours(srcbit);
 
     // ---- one-hive test (move_checker.py:58-83 / env_hive.py:509-530): flood the hive without
     // the mover from one of its neighbours until every neighbour is reached or nothing grows.
-    BB target = bb_and(bb_neighbours(srcbit), occp);
-    bool pinned = on_top && !stacked && !bb_any(target);    // lone piece: empty board => False
-    bool act = on_top && !stacked && bb_any(target);
+    BB target = bb_and(nsrc, occp);
+    const bool has_nb = bb_any(target);
+    bool pinned = on_top && !stacked && !has_nb;    // lone piece: empty board => False
+    bool act = on_top && !stacked && has_nb;
     BB reach = bb_lowest(target);
     while (__any(act)) {
         if (act) {
@@ -168,8 +151,7 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     BB rule = bb_zero();
     if (type == T_GRASS) {
         // pieces.py:128-158: flood from src through occupied cells on a "line" from src
-        unsigned lc = on_board ? c : 0u;
-        BB L = lds_bb(line[lc]);
+        BB L = bb_load(d_tables.line[on_board ? c : 0u]);
         BB Lo = bb_and(L, occ);
         BB V = srcbit;
         bool ga = movable;
@@ -180,9 +162,11 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 V = nx;
             }
         }
-        rule = bb_andn(bb_and(bb_andn(bb_neighbours(V), occ), L), bb_neighbours(srcbit));
+        rule = bb_andn(bb_and(bb_andn(bb_neighbours(V), occ), L), nsrc);
     } else {
-        SlideCtx ctx = make_slide_ctx(occp);
+        BB S[6];
+        occupancy_views(occp, S);
+        SlideCtx ctx = make_slide_ctx(occp, S);
         if (type == T_QUEEN) {
             rule = slide_step(ctx, srcbit);                       // pieces.py:35-44
         } else if (type == T_ANT) {
@@ -198,12 +182,11 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
             rule = bb_andn(R, srcbit);
         } else {
             // both flanks occupied (k == 2) per direction
-            BB S[6];
-            occupancy_views(occp, S);
             BB b0 = bb_and(S[5], S[1]), b1 = bb_and(S[0], S[2]), b2 = bb_and(S[1], S[3]);
             BB b3 = bb_and(S[2], S[4]), b4 = bb_and(S[3], S[5]), b5 = bb_and(S[4], S[0]);
             if (type == T_SPIDER) {
-                // pieces.py:78-85: simple path of exactly three k==1 steps, then the direct-hop veto
+                // pieces.py:78-85: simple path of exactly three k==1 steps, then the direct-hop veto.
+                // For each first step a: {c} = slide(slide(a) \ src) \ {src, a}; c != b holds by itself.
                 BB A = slide_step(ctx, srcbit);
                 BB acc = bb_zero();
                 bool sa = movable && bb_any(A);
@@ -222,18 +205,12 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 rule = bb_andn(acc, veto);
             } else {
                 // Beetle, pieces.py:100-113 + move_checker.py:201-209
-                BB P = bb_neighbours(srcbit);
                 BB Q1 = slide_raw(ctx, srcbit);
-                BB k0[6];
-                k0[0] = bb_andn(bb_andn(srcbit, ctx.cs[0]), b0);
-                k0[1] = bb_andn(bb_andn(srcbit, ctx.cs[1]), b1);
-                k0[2] = bb_andn(bb_andn(srcbit, ctx.cs[2]), b2);
-                k0[3] = bb_andn(bb_andn(srcbit, ctx.cs[3]), b3);
-                k0[4] = bb_andn(bb_andn(srcbit, ctx.cs[4]), b4);
-                k0[5] = bb_andn(bb_andn(srcbit, ctx.cs[5]), b5);
-                BB Q0 = shift_dirs(k0[0], k0[1], k0[2], k0[3], k0[4], k0[5]);
-                rule = bb_or(bb_or(bb_and(P, occ), Q1), bb_and(Q0, ctx.nocc));
-                if (stacked) rule = bb_or(rule, P);
+                BB Q0 = shift_dirs(bb_andn(bb_andn(srcbit, ctx.cs[0]), b0), bb_andn(bb_andn(srcbit, ctx.cs[1]), b1),
+                                   bb_andn(bb_andn(srcbit, ctx.cs[2]), b2), bb_andn(bb_andn(srcbit, ctx.cs[3]), b3),
+                                   bb_andn(bb_andn(srcbit, ctx.cs[4]), b4), bb_andn(bb_andn(srcbit, ctx.cs[5]), b5));
+                rule = bb_or3(bb_and(nsrc, occ), Q1, bb_and(Q0, ctx.nocc));
+                if (stacked) rule = bb_or(rule, nsrc);
             }
         }
     }
@@ -266,7 +243,7 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 else if (turn == 2u) D = bb_and(base, nocc);
                 else if (gate) {
                     // placement_is_allowed (move_checker.py:168-179): no neighbour topped by the other colour
-                    BB topw = lds_bb(topw_p);
+                    BB topw = bb_load(topw_p);
                     BB top_enemy = color == 0 ? bb_andn(occ, topw) : topw;
                     D = bb_andn(bb_and(base, nocc), bb_neighbours(top_enemy));
                 }
@@ -275,11 +252,11 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     } else if (movable) {
         const bool adjacent_domain = (type == T_QUEEN || type == T_BEETLE);
         BB domain;
-        if (!own) domain = bb_not(bb_zero());
-        else if (adjacent_domain) domain = bb_neighbours(srcbit);
+        if (!own) domain = bb_full();
+        else if (adjacent_domain) domain = nsrc;
         else domain = nmt;
         if (turn <= 2u) {
-            BB base = bb_andn(type == T_BEETLE ? bb_not(bb_zero()) : bb_not(occ), srcbit);
+            BB base = bb_andn(type == T_BEETLE ? bb_full() : bb_not(occ), srcbit);
             D = bb_and(domain, base);
             D = bb_and(D, turn == 1u ? bb_bit((unsigned)kStartCell) : nocc);
         } else if (gate) {
@@ -330,12 +307,13 @@ hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restr
     constexpr bool ENC = FULL;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int bl = FULL ? (lane & 31) : lane;      // board of this lane inside the workgroup
+    const int item = lane >> 2;                      // quad index inside the wave
+    const int bl = FULL ? (item & 7) : item;         // board of this quad inside the workgroup
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nthreads = NW * 64;
     const long long gbase = (long long)blockIdx.x * G;
 
-    // ---------------- phase 0: stage records + LUTs, clear accumulators
+    // ---------------- phase 0: stage records, clear accumulators
     for (int i = tid; i < G * 4; i += nthreads) {
         int b = i >> 2, part = i & 3;
         uint4 v;
@@ -350,11 +328,11 @@ hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restr
         (&sm.occ[0][0])[i] = 0u;
         (&sm.topw[0][0])[i] = 0u;
     }
-    for (int i = tid; i < kCells * 6; i += nthreads) (&sm.line[0][0])[i] = (&d_tables.line[0][0])[i];
-    for (int i = tid; i < kCells * 2; i += nthreads)
-        reinterpret_cast<uint32_t *>(&sm.nbr[0][0])[i] = reinterpret_cast<const uint32_t *>(&d_tables.nbr[0][0])[i];
-    if (ENC)
+    if (ENC) {
+        for (int i = tid; i < kCells * 2; i += nthreads)
+            reinterpret_cast<uint32_t *>(&sm.nbr[0][0])[i] = reinterpret_cast<const uint32_t *>(&d_tables.nbr[0][0])[i];
         for (int i = tid; i < G * kCells; i += nthreads) (&sm.feat[0][0])[i] = 0ull;
+    }
     __syncthreads();
 
     // occupancy and top-colour boards: every (board, piece) pair ORs its bit in
@@ -374,10 +352,8 @@ hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restr
         }
     }
     __syncthreads();
-    if (tid < G) lds_store_bb(sm.nocc[tid], bb_neighbours(lds_bb(sm.occ[tid])));
-    __syncthreads();
 
-    // ---------------- phase 1: one lane per (board, piece), one piece slot per wave
+    // ---------------- phase 1: one quad per (board, piece), one piece slot per wave
     const bool valid = gbase + bl < n;
     const uint32_t *st = sm.state[bl];
     const unsigned turn = state_byte(st, 33);
@@ -386,14 +362,17 @@ hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restr
     int q, di;
     bool own;
     if (!FULL) { q = stm * 11 + wv; di = wv; own = true; }
-    else { int col = lane >> 5; q = col * 11 + wv; di = q; own = (col == stm); }
-    PieceInfo pc = piece_dests(st, sm.occ[bl], sm.topw[bl], sm.nocc[bl], sm.line, q, type, own, valid);
-    lds_store_bb(sm.dest[di][bl], pc.D);
+    else { int col = item >> 3; q = col * 11 + wv; di = q; own = (col == stm); }
+    PieceInfo pc = piece_dests(st, sm.occ[bl], sm.topw[bl], q, type, own, valid);
+    bb_store(&sm.dest[di][bl * 6], pc.D);
+    const bool d_any = bb_any(pc.D);
+    __syncthreads();
 
     if (ENC) {
-        // ---------------- planes: per-piece feature bits (env_hive.py:352-429)
+        // ---------------- planes: per-piece feature bits (env_hive.py:352-429), one lane per quad
         const int color = q >= 11 ? 1 : 0, slot = q - 11 * color;
-        if (pc.on_board) {
+        if (pc.on_board && (lane & 3) == 0) {
+            const uint32_t *myd = &sm.dest[di][bl * 6];
             unsigned long long bits = 0ull;
             const unsigned base_own = own ? 0u : 12u;
             bits |= 1ull << (base_own + (unsigned)slot);
@@ -406,12 +385,12 @@ hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restr
                 if (pc.lvl == 4u && pc.h == 5u) bits |= 1ull << (bb + 2u);
             }
             if (own) {
-                if (!pc.on_top || !bb_any(pc.D)) bits |= 1ull << 34;
+                if (!pc.on_top || !d_any) bits |= 1ull << 34;
                 unsigned eq = state_byte(st, (unsigned)((1 - stm) * 11));
                 if (pc.on_top && eq < (unsigned)kCells) {
                     for (int i = 0; i < 6; ++i) {
                         unsigned adj = sm.nbr[eq][i];
-                        if (!lds_test(sm.occ[bl], adj) && lds_test(sm.dest[di][bl], adj)) bits |= 1ull << (50 + i);
+                        if (!lds_test(sm.occ[bl], adj) && lds_test(myd, adj)) bits |= 1ull << (50 + i);
                     }
                 }
             } else {
@@ -420,7 +399,7 @@ hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restr
                 if (pc.on_top && !pc.pinned && oq < (unsigned)kCells) {
                     for (int i = 0; i < 6; ++i) {
                         unsigned adj = sm.nbr[oq][i];
-                        if (!lds_test(sm.occ[bl], adj) && lds_test(sm.dest[di][bl], adj)) bits |= 1ull << (44 + i);
+                        if (!lds_test(sm.occ[bl], adj) && lds_test(myd, adj)) bits |= 1ull << (44 + i);
                     }
                 }
             }
@@ -433,7 +412,7 @@ hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restr
                 }
             }
         }
-        // history planes 36..43 (env_hive.py:431-434): 64 boards x 8 boards-of-bits
+        // history planes 36..43 (env_hive.py:431-434): G boards x 8 boards-of-bits
         if (tid < G * 8) {
             int b = tid % G, hidx = tid / G;
             if (gbase + b < n && hist != nullptr) {
@@ -458,7 +437,6 @@ hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restr
             }
         }
     }
-    __syncthreads();
 
     // ---------------- phase 2: 25 ballots per board -> 1584-bit mask, count, sorted id list
     if (mask != nullptr || count != nullptr || list != nullptr) {
@@ -472,7 +450,7 @@ hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restr
                 unsigned a = (unsigned)(t * 64 + lane);
                 unsigned cell = a / 11u, slot = a - cell * 11u;
                 bool pred = false;
-                if (a < (unsigned)HIVE_ACTIONS) pred = lds_test(sm.dest[qbase + slot][b], cell);
+                if (a < (unsigned)HIVE_ACTIONS) pred = lds_test(&sm.dest[qbase + slot][b * 6], cell);
                 unsigned long long m = __ballot(pred);
                 if (lane == t) mine = m;
                 if (list != nullptr && pred) {
@@ -491,6 +469,7 @@ hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restr
 
     // ---------------- phase 3: expand the 56 feature bits per cell into the plane tensor
     if (ENC && planes != nullptr) {
+        __syncthreads();
         using V = typename std::conditional<DT == 0, float, typename std::conditional<DT == 1, half_tag, bf16_tag>::type>::type;
         const uint32_t one = PlaneVal<V>::one();
         constexpr int kItems = kCells * HIVE_PLANES / 8;    // 8 consecutive elements per item
@@ -690,11 +669,11 @@ static int launch_env(const HiveBoard *boards, const HiveHistory *hist, int n, u
     if (n <= 0 || boards == nullptr) return fail(HIVE_E_ARG, "launch_env: n <= 0 or boards == NULL");
     unsigned long long *m64 = reinterpret_cast<unsigned long long *>(mask);
     if (planes == nullptr) {
-        dim3 grid((unsigned)((n + 63) / 64));
+        dim3 grid((unsigned)((n + 15) / 16));
         hipLaunchKernelGGL((hive_env_kernel<false, 0, 0>), grid, dim3(NW * 64), 0, stream, boards, hist, n, m64,
                            count, list, nullptr);
     } else {
-        dim3 grid((unsigned)((n + 31) / 32));
+        dim3 grid((unsigned)((n + 7) / 8));
 #define HIVE_ENC_CASE(DT, LY)                                                                              \
     if (dtype == DT && layout == LY)                                                                       \
         hipLaunchKernelGGL((hive_env_kernel<true, DT, LY>), grid, dim3(NW * 64), 0, stream, boards, hist, n, \
