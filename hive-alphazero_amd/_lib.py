@@ -78,7 +78,7 @@ def load():
     L.hive_batch_export.argtypes = [vp, vp, vp]
     L.hive_batch_import.argtypes = [vp, vp, vp]
     L.hive_movegen_launch.argtypes = [vp, i32, vp, vp, vp, vp]
-    L.hive_encode_launch.argtypes = [vp, vp, i32, vp, i32, i32, vp]
+    L.hive_encode_launch.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.hive_debug_tables.argtypes = [vp, vp, vp]
     for name in ABI_SYMBOLS:
         getattr(L, name)

@@ -51,27 +51,18 @@ __device__ __forceinline__ int slot_group_start(int slot)
 template <bool FULL>
 struct Smem {
     static constexpr int G = FULL ? 8 : 16;
-    static constexpr int ND = FULL ? 22 : 11;
-    static constexpr int DSTRIDE = G * 6 + 1;   // +1 word: the 11 slots of one cell land in 11 banks
     uint32_t state[G][16];       // HiveBoard records
     uint32_t occ[G][6];          // cells with at least one piece
     uint32_t topw[G][6];         // cells whose top piece is white
-    uint32_t dest[ND][DSTRIDE];  // destination board of piece d on board g at [d][g*6 ..]
-    uint8_t nbr[FULL ? kCells : 1][8];                           // adjacent_tiles order LUT
+    uint32_t mask[G][HIVE_MASK_WORDS];                          // legal mask being assembled
     unsigned long long feat[FULL ? G : 1][FULL ? kCells : 1];   // 56 feature bits per cell
+    int done;                    // waves that have delivered their destinations
 };
 
 __device__ __forceinline__ unsigned state_byte(const uint32_t *st, unsigned idx)
 {
     return reinterpret_cast<const uint8_t *>(st)[idx];
 }
-__device__ __forceinline__ bool lds_test(const uint32_t *bbp, unsigned cell)
-{
-    unsigned wi, bit;
-    cell_word_bit(cell, wi, bit);
-    return (bbp[wi] >> bit) & 1u;
-}
-
 // move_checker.py:106-137
 __device__ __forceinline__ bool obeys_queen_by_4(unsigned turn, int nq, int first_color, bool mover_queen,
                                                  int mover_color)
@@ -273,38 +264,37 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     return out;
 }
 
-// value encoders for the plane writer
-template <typename T> struct PlaneVal;
-template <> struct PlaneVal<float> {
-    static __device__ __forceinline__ uint32_t one() { return 0x3F800000u; }
-    static __device__ __forceinline__ uint32_t of(unsigned v) { return __float_as_uint((float)v); }
-};
-struct half_tag {};
-struct bf16_tag {};
-template <> struct PlaneVal<half_tag> {
-    static __device__ __forceinline__ uint32_t one() { return 0x3C00u; }
-    static __device__ __forceinline__ uint32_t of(unsigned v)
-    {
-        _Float16 hval = (_Float16)(float)v;
-        return (uint32_t) __builtin_bit_cast(unsigned short, hval);
-    }
-};
-template <> struct PlaneVal<bf16_tag> {
-    static __device__ __forceinline__ uint32_t one() { return 0x3F80u; }
-    static __device__ __forceinline__ uint32_t of(unsigned v) { return __float_as_uint((float)v) >> 16; }   // v <= 255: exact
-};
+// cell test on a lane-distributed board (result replicated over the quad)
+__device__ __forceinline__ bool bb_test(BB x, unsigned cell) { return bb_any(bb_and(x, bb_bit(cell))); }
 
-// FULL = false: movegen for the side to move.  FULL = true: both colours + the 56 planes.
-// DT: 0 f32, 1 f16, 2 bf16 (only used when FULL).
-template <bool FULL, int DT, int LAYOUT>
+// OR the set cells of this lane's two words of D into the board's 1584-bit mask: bit cell*11+slot
+__device__ __forceinline__ void scatter_dests(uint32_t *mrow, BB D, int slot)
+{
+    const int l = quad_lane();
+    HIVE_UNROLL for (int half = 0; half < 2; ++half) {
+        uint32_t w = half ? D.hi : D.lo;
+        const unsigned row0 = 4u * (unsigned)l + 2u * (unsigned)half;
+        while (w) {
+            unsigned bit = __builtin_ctz(w);
+            w &= w - 1u;
+            unsigned a = ((row0 + (bit >> 4)) * 12u + (bit & 15u)) * 11u + (unsigned)slot;
+            atomicOr(&mrow[a >> 5], 1u << (a & 31u));
+        }
+    }
+}
+
+// The piece kernel.  FULL = false: legal mask/count of the side to move (GamePlay.actions).
+// FULL = true: both colours; additionally the 56 feature bits per cell (planes 0-35, 44-55 of
+// GamePlay.make_state_value; history planes 36-43 and plane 31 are added by hive_expand_kernel).
+// There is no barrier after the piece work: each wave ORs its results into LDS and leaves; the
+// last wave to finish writes the workgroup's boards out.
+template <bool FULL>
 __global__ void __launch_bounds__(NW * 64)
-hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restrict__ hist, int n,
-                unsigned long long *__restrict__ mask, int32_t *__restrict__ count, int16_t *__restrict__ list,
-                void *__restrict__ planes)
+hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restrict__ mask,
+                  int32_t *__restrict__ count, unsigned long long *__restrict__ feat)
 {
     __shared__ Smem<FULL> sm;
     constexpr int G = Smem<FULL>::G;
-    constexpr bool ENC = FULL;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int item = lane >> 2;                      // quad index inside the wave
@@ -328,11 +318,10 @@ hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restr
         (&sm.occ[0][0])[i] = 0u;
         (&sm.topw[0][0])[i] = 0u;
     }
-    if (ENC) {
-        for (int i = tid; i < kCells * 2; i += nthreads)
-            reinterpret_cast<uint32_t *>(&sm.nbr[0][0])[i] = reinterpret_cast<const uint32_t *>(&d_tables.nbr[0][0])[i];
+    for (int i = tid; i < G * HIVE_MASK_WORDS; i += nthreads) (&sm.mask[0][0])[i] = 0u;
+    if (FULL)
         for (int i = tid; i < G * kCells; i += nthreads) (&sm.feat[0][0])[i] = 0ull;
-    }
+    if (tid == 0) sm.done = 0;
     __syncthreads();
 
     // occupancy and top-colour boards: every (board, piece) pair ORs its bit in
@@ -359,23 +348,41 @@ hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restr
     const unsigned turn = state_byte(st, 33);
     const int stm = (turn & 1u) ? 0 : 1;
     const int type = slot_type(wv);
-    int q, di;
+    int q;
     bool own;
-    if (!FULL) { q = stm * 11 + wv; di = wv; own = true; }
-    else { int col = item >> 3; q = col * 11 + wv; di = q; own = (col == stm); }
+    if (!FULL) { q = stm * 11 + wv; own = true; }
+    else { int col = item >> 3; q = col * 11 + wv; own = (col == stm); }
     PieceInfo pc = piece_dests(st, sm.occ[bl], sm.topw[bl], q, type, own, valid);
-    bb_store(&sm.dest[di][bl * 6], pc.D);
-    const bool d_any = bb_any(pc.D);
-    __syncthreads();
+    if (own && (mask != nullptr || count != nullptr)) scatter_dests(sm.mask[bl], pc.D, wv);
 
-    if (ENC) {
-        // ---------------- planes: per-piece feature bits (env_hive.py:352-429), one lane per quad
-        const int color = q >= 11 ? 1 : 0, slot = q - 11 * color;
+    if (FULL) {
+        // ---------------- per-piece feature bits (env_hive.py:352-429)
+        const BB occ = bb_load(sm.occ[bl]);
+        const bool d_any = bb_any(pc.D);
+        unsigned long long bits = 0ull;
+        if (own) {
+            if (!pc.on_top || !d_any) bits |= 1ull << 34;
+            unsigned eq = state_byte(st, (unsigned)((1 - stm) * 11));      // enemy queen
+            if (pc.on_top && eq < (unsigned)kCells)
+                for (int i = 0; i < 6; ++i) {
+                    unsigned adj = d_tables.nbr[eq][i];
+                    if (!bb_test(occ, adj) && bb_test(pc.D, adj)) bits |= 1ull << (50 + i);
+                }
+        } else {
+            if (!pc.on_top || pc.pinned) bits |= 1ull << 35;
+            unsigned oq = state_byte(st, (unsigned)(stm * 11));            // own queen
+            if (pc.on_top && !pc.pinned && oq < (unsigned)kCells)
+                for (int i = 0; i < 6; ++i) {
+                    unsigned adj = d_tables.nbr[oq][i];
+                    if (!bb_test(occ, adj) && bb_test(pc.D, adj)) bits |= 1ull << (44 + i);
+                }
+        }
+        unsigned qnb = 0u;     // occupied neighbours of a queen, by adjacent_tiles index
+        if (type == T_QUEEN && pc.on_board)
+            for (int i = 0; i < 6; ++i) qnb |= bb_test(occ, d_tables.nbr[pc.cell][i]) ? (1u << i) : 0u;
         if (pc.on_board && (lane & 3) == 0) {
-            const uint32_t *myd = &sm.dest[di][bl * 6];
-            unsigned long long bits = 0ull;
-            const unsigned base_own = own ? 0u : 12u;
-            bits |= 1ull << (base_own + (unsigned)slot);
+            const int slot = wv;
+            bits |= 1ull << ((own ? 0u : 12u) + (unsigned)slot);
             bits |= 1ull << (own ? 11u : 23u);
             bits |= 1ull << 30;
             if (type == T_BEETLE) {
@@ -384,120 +391,148 @@ hive_env_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restr
                 if (pc.lvl == 3u) bits |= 1ull << (bb + 1u);
                 if (pc.lvl == 4u && pc.h == 5u) bits |= 1ull << (bb + 2u);
             }
-            if (own) {
-                if (!pc.on_top || !d_any) bits |= 1ull << 34;
-                unsigned eq = state_byte(st, (unsigned)((1 - stm) * 11));
-                if (pc.on_top && eq < (unsigned)kCells) {
-                    for (int i = 0; i < 6; ++i) {
-                        unsigned adj = sm.nbr[eq][i];
-                        if (!lds_test(sm.occ[bl], adj) && lds_test(myd, adj)) bits |= 1ull << (50 + i);
-                    }
-                }
-            } else {
-                if (!pc.on_top || pc.pinned) bits |= 1ull << 35;
-                unsigned oq = state_byte(st, (unsigned)(stm * 11));
-                if (pc.on_top && !pc.pinned && oq < (unsigned)kCells) {
-                    for (int i = 0; i < 6; ++i) {
-                        unsigned adj = sm.nbr[oq][i];
-                        if (!lds_test(sm.occ[bl], adj) && lds_test(myd, adj)) bits |= 1ull << (44 + i);
-                    }
-                }
-            }
             atomicOr(&sm.feat[bl][pc.cell], bits);
             if (type == T_QUEEN) {
                 const unsigned long long qb = 1ull << (own ? 32 : 33);
-                for (int i = 0; i < 6; ++i) {
-                    unsigned adj = sm.nbr[pc.cell][i];
-                    if (lds_test(sm.occ[bl], adj)) atomicOr(&sm.feat[bl][adj], qb);
-                }
-            }
-        }
-        // history planes 36..43 (env_hive.py:431-434): G boards x 8 boards-of-bits
-        if (tid < G * 8) {
-            int b = tid % G, hidx = tid / G;
-            if (gbase + b < n && hist != nullptr) {
-                const uint32_t *sb = sm.state[b];
-                unsigned t = state_byte(sb, 33), hl = state_byte(sb, 35);
-                int persp = (t & 1u) ? 0 : 1;
-                unsigned len = persp == 0 ? (hl & 15u) : (hl >> 4);
-                int age = hidx >> 1, k = hidx & 1;
-                if ((unsigned)age < len) {
-                    const uint32_t *src = hist[gbase + b].m[persp][age][k];
-                    const unsigned long long pb = 1ull << (36 + hidx);
-                    for (int w = 0; w < 6; ++w) {
-                        uint32_t word = src[w];
-                        while (word) {
-                            unsigned bit = __builtin_ctz(word);
-                            word &= word - 1u;
-                            unsigned cell = (2u * w + (bit >> 4)) * 12u + (bit & 15u);
-                            atomicOr(&sm.feat[b][cell], pb);
-                        }
-                    }
-                }
+                for (int i = 0; i < 6; ++i)
+                    if ((qnb >> i) & 1u) atomicOr(&sm.feat[bl][d_tables.nbr[pc.cell][i]], qb);
             }
         }
     }
 
-    // ---------------- phase 2: 25 ballots per board -> 1584-bit mask, count, sorted id list
-    if (mask != nullptr || count != nullptr || list != nullptr) {
-        for (int b = wv; b < G; b += NW) {
-            if (gbase + b >= n) break;
-            const unsigned tb = state_byte(sm.state[b], 33);
-            const int qbase = FULL ? (((tb & 1u) ? 0 : 1) * 11) : 0;
-            unsigned long long mine = 0ull;
-            int total = 0;
-            for (int t = 0; t < 25; ++t) {
-                unsigned a = (unsigned)(t * 64 + lane);
-                unsigned cell = a / 11u, slot = a - cell * 11u;
-                bool pred = false;
-                if (a < (unsigned)HIVE_ACTIONS) pred = lds_test(&sm.dest[qbase + slot][b * 6], cell);
-                unsigned long long m = __ballot(pred);
-                if (lane == t) mine = m;
-                if (list != nullptr && pred) {
-                    int p = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (p < HIVE_LIST_CAP) list[(gbase + b) * HIVE_LIST_CAP + p] = (int16_t)a;
-                }
-                total += __popcll(m);
-            }
-            if (mask != nullptr && lane < 25) mask[(gbase + b) * 25 + lane] = mine;
-            if (count != nullptr && lane == 0) count[gbase + b] = total;
-            if (list != nullptr)
-                for (int p = total + lane; p < HIVE_LIST_CAP; p += 64) list[(gbase + b) * HIVE_LIST_CAP + p] = -1;
+    // ---------------- tail: the last wave to arrive writes the workgroup's results
+    int prior = 0;
+    if (lane == 0) prior = __hip_atomic_fetch_add(&sm.done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    prior = __builtin_amdgcn_readfirstlane(prior);
+    if (prior != NW - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    const int nb = (int)((n - gbase) < G ? (n - gbase) : G);
+    if (mask != nullptr)
+        for (int i = lane; i < nb * HIVE_MASK_WORDS; i += 64) mask[gbase * HIVE_MASK_WORDS + i] = (&sm.mask[0][0])[i];
+    if (count != nullptr) {
+        // 4 lanes per board sum the popcounts of its 50 words
+        for (int b0 = 0; b0 < G; b0 += 16) {
+            int b = b0 + (lane >> 2), l4 = lane & 3;
+            uint32_t c = 0;
+            if (b < G)
+                for (int w = l4; w < HIVE_MASK_WORDS; w += 4) c += (uint32_t)__popc(sm.mask[b][w]);
+            c += quad<kQuadSwap1>(c);
+            c += quad<kQuadSwap2>(c);
+            if (b < nb && l4 == 0) count[gbase + b] = (int32_t)c;
         }
     }
+    if (FULL && feat != nullptr) {
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(&sm.feat[0][0]);
+        ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(feat + gbase * kCells);
+        for (int i = lane; i < nb * (kCells / 2); i += 64) dst[i] = src[i];
+    }
+}
 
-    // ---------------- phase 3: expand the 56 feature bits per cell into the plane tensor
-    if (ENC && planes != nullptr) {
-        __syncthreads();
-        using V = typename std::conditional<DT == 0, float, typename std::conditional<DT == 1, half_tag, bf16_tag>::type>::type;
-        const uint32_t one = PlaneVal<V>::one();
-        constexpr int kItems = kCells * HIVE_PLANES / 8;    // 8 consecutive elements per item
-        for (int it = tid; it < G * kItems; it += nthreads) {
-            int b = it / kItems, e0 = (it - b * kItems) * 8;
-            if (gbase + b >= n) break;
-            const uint32_t tv = PlaneVal<V>::of(state_byte(sm.state[b], 33));
-            uint32_t v[8];
-            if (LAYOUT == HIVE_HWC) {
-                int cell = e0 / HIVE_PLANES, p0 = e0 - cell * HIVE_PLANES;
-                unsigned bits8 = (unsigned)(sm.feat[b][cell] >> p0) & 0xFFu;
-                HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = ((bits8 >> k) & 1u) ? one : 0u;
-                if (p0 == 24) v[7] = tv;      // plane 31 = raw turn number (env_hive.py:331)
-            } else {
-                int p = e0 / kCells, c0 = e0 - p * kCells;
-                HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = ((sm.feat[b][c0 + k] >> p) & 1ull) ? one : 0u;
-                if (p == 31) { HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = tv; }
-            }
-            const long long eoff = (gbase + b) * (long long)(kCells * HIVE_PLANES) + e0;
-            if (DT == 0) {
-                uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<float *>(planes) + eoff);
-                dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
-                dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
-            } else {
-                uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(planes) + eoff);
-                dst[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+// Sorted legal-id lists from the 1584-bit masks: one wave per board, the mask word IS the ballot
+// of the predicate "action 64 t + lane is legal", v_mbcnt gives each lane its slot in the list.
+__global__ void __launch_bounds__(256)
+hive_list_kernel(const unsigned long long *__restrict__ mask, int n, int16_t *__restrict__ list)
+{
+    const int lane = threadIdx.x & 63;
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const unsigned long long *m = mask + b * 25;
+    int16_t *row = list + b * HIVE_LIST_CAP;
+    int total = 0;
+    for (int t = 0; t < 25; ++t) {
+        unsigned long long w = m[t];
+        if ((w >> lane) & 1ull) {
+            int p = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(w >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)w, 0u));
+            if (p < HIVE_LIST_CAP) row[p] = (int16_t)(t * 64 + lane);
+        }
+        total += __popcll(w);
+    }
+    for (int p = total + lane; p < HIVE_LIST_CAP; p += 64) row[p] = -1;
+}
+
+// value encoders for the plane writer
+template <typename T> struct PlaneVal;
+template <> struct PlaneVal<float> {
+    static __device__ __forceinline__ uint32_t one() { return 0x3F800000u; }
+    static __device__ __forceinline__ uint32_t of(unsigned v) { return __float_as_uint((float)v); }
+};
+struct half_tag {};
+struct bf16_tag {};
+template <> struct PlaneVal<half_tag> {
+    static __device__ __forceinline__ uint32_t one() { return 0x3C00u; }
+    static __device__ __forceinline__ uint32_t of(unsigned v)
+    {
+        _Float16 hval = (_Float16)(float)v;
+        return (uint32_t) __builtin_bit_cast(unsigned short, hval);
+    }
+};
+template <> struct PlaneVal<bf16_tag> {
+    static __device__ __forceinline__ uint32_t one() { return 0x3F80u; }
+    static __device__ __forceinline__ uint32_t of(unsigned v) { return __float_as_uint((float)v) >> 16; }   // v <= 255: exact
+};
+
+// Packed features (56 bits per cell) + history boards + turn -> the plane tensor.  One thread
+// writes 8 consecutive elements (16 B of f16/bf16, 32 B of f32); pure streaming store kernel.
+template <int DT, int LAYOUT>
+__global__ void __launch_bounds__(256)
+hive_expand_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restrict__ hist,
+                   const unsigned long long *__restrict__ feat, int n, void *__restrict__ planes)
+{
+    using V = typename std::conditional<DT == 0, float, typename std::conditional<DT == 1, half_tag, bf16_tag>::type>::type;
+    constexpr int kItems = kCells * HIVE_PLANES / 8;
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long b = g / kItems;
+    if (b >= n) return;
+    const int e0 = (int)(g - b * kItems) * 8;
+    const uint32_t one = PlaneVal<V>::one();
+    const uint32_t meta = reinterpret_cast<const uint32_t *>(&boards[b])[8];    // bytes 32..35
+    const unsigned turn = (meta >> 8) & 0xFFu, hl = meta >> 24;
+    const int persp = (turn & 1u) ? 0 : 1;
+    const unsigned hlen = persp == 0 ? (hl & 15u) : (hl >> 4);
+    const uint32_t tv = PlaneVal<V>::of(turn);
+    uint32_t v[8];
+    if (LAYOUT == HIVE_HWC) {
+        const int cell = e0 / HIVE_PLANES, p0 = e0 - cell * HIVE_PLANES;
+        unsigned bits8 = (unsigned)(feat[b * kCells + cell] >> p0) & 0xFFu;
+        if (p0 >= 32 && p0 < 48 && hist != nullptr) {
+            // history planes 36..43 = (own, enemy) occupancy 1..4 encodes ago (env_hive.py:431-434)
+            unsigned wi, bit;
+            cell_word_bit((unsigned)cell, wi, bit);
+            HIVE_UNROLL for (int k = 0; k < 8; ++k) {
+                int p = p0 + k;
+                if (p >= 36 && p < 44 && (unsigned)((p - 36) >> 1) < hlen)
+                    bits8 |= ((hist[b].m[persp][(p - 36) >> 1][(p - 36) & 1][wi] >> bit) & 1u) << k;
             }
         }
+        HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = ((bits8 >> k) & 1u) ? one : 0u;
+        if (p0 == 24) v[7] = tv;      // plane 31 = raw turn number (env_hive.py:331)
+    } else {
+        const int p = e0 / kCells, c0 = e0 - p * kCells;
+        if (p >= 36 && p < 44) {
+            unsigned hb = 0u;
+            if (hist != nullptr && (unsigned)((p - 36) >> 1) < hlen) {
+                const uint32_t *hw = hist[b].m[persp][(p - 36) >> 1][(p - 36) & 1];
+                HIVE_UNROLL for (int k = 0; k < 8; ++k) {
+                    unsigned wi, bit;
+                    cell_word_bit((unsigned)(c0 + k), wi, bit);
+                    hb |= ((hw[wi] >> bit) & 1u) << k;
+                }
+            }
+            HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = ((hb >> k) & 1u) ? one : 0u;
+        } else {
+            HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = ((feat[b * kCells + c0 + k] >> p) & 1ull) ? one : 0u;
+        }
+        if (p == 31) { HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = tv; }
+    }
+    const long long eoff = b * (long long)(kCells * HIVE_PLANES) + e0;
+    if (DT == 0) {
+        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<float *>(planes) + eoff);
+        dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
+    } else {
+        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(planes) + eoff);
+        dst[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
     }
 }
 
@@ -648,6 +683,7 @@ struct HiveBatch {
     int32_t *legal_count = nullptr;
     int16_t *legal_list = nullptr;
     bool legal_valid = false;
+    unsigned long long *feat = nullptr;     // packed-feature workspace of the encoder
     unsigned long long *illegal = nullptr;  // device counter
 };
 
@@ -663,40 +699,52 @@ int hive_device_count(void)
     return c;
 }
 
-static int launch_env(const HiveBoard *boards, const HiveHistory *hist, int n, uint32_t *mask, int32_t *count,
-                      int16_t *list, void *planes, int dtype, int layout, hipStream_t stream)
+static int launch_pieces(const HiveBoard *boards, int n, uint32_t *mask, int32_t *count, int16_t *list,
+                         hipStream_t stream)
 {
-    if (n <= 0 || boards == nullptr) return fail(HIVE_E_ARG, "launch_env: n <= 0 or boards == NULL");
-    unsigned long long *m64 = reinterpret_cast<unsigned long long *>(mask);
-    if (planes == nullptr) {
-        dim3 grid((unsigned)((n + 15) / 16));
-        hipLaunchKernelGGL((hive_env_kernel<false, 0, 0>), grid, dim3(NW * 64), 0, stream, boards, hist, n, m64,
-                           count, list, nullptr);
-    } else {
-        dim3 grid((unsigned)((n + 7) / 8));
-#define HIVE_ENC_CASE(DT, LY)                                                                              \
-    if (dtype == DT && layout == LY)                                                                       \
-        hipLaunchKernelGGL((hive_env_kernel<true, DT, LY>), grid, dim3(NW * 64), 0, stream, boards, hist, n, \
-                           m64, count, list, planes);
-        if (dtype < 0 || dtype > 2 || layout < 0 || layout > 1) return fail(HIVE_E_ARG, "unknown dtype/layout");
-        HIVE_ENC_CASE(0, 0) HIVE_ENC_CASE(0, 1) HIVE_ENC_CASE(1, 0) HIVE_ENC_CASE(1, 1) HIVE_ENC_CASE(2, 0)
-        HIVE_ENC_CASE(2, 1)
-#undef HIVE_ENC_CASE
+    if (n <= 0 || boards == nullptr) return fail(HIVE_E_ARG, "movegen: n <= 0 or boards == NULL");
+    if (list != nullptr && mask == nullptr) return fail(HIVE_E_ARG, "movegen: the id list needs the mask buffer too");
+    hipLaunchKernelGGL((hive_piece_kernel<false>), dim3((unsigned)((n + 15) / 16)), dim3(NW * 64), 0, stream, boards, n,
+                       mask, count, (unsigned long long *)nullptr);
+    HIP_TRY(hipGetLastError());
+    if (list != nullptr) {
+        hipLaunchKernelGGL(hive_list_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream,
+                           reinterpret_cast<const unsigned long long *>(mask), n, list);
+        HIP_TRY(hipGetLastError());
     }
+    return HIVE_OK;
+}
+
+static int launch_encode(const HiveBoard *boards, const HiveHistory *hist, int n, void *planes, int dtype, int layout,
+                         unsigned long long *feat, hipStream_t stream)
+{
+    if (n <= 0 || boards == nullptr || planes == nullptr || feat == nullptr)
+        return fail(HIVE_E_ARG, "encode: n <= 0 or a NULL buffer");
+    if (dtype < 0 || dtype > 2 || layout < 0 || layout > 1) return fail(HIVE_E_ARG, "encode: unknown dtype/layout");
+    hipLaunchKernelGGL((hive_piece_kernel<true>), dim3((unsigned)((n + 7) / 8)), dim3(NW * 64), 0, stream, boards, n,
+                       (uint32_t *)nullptr, (int32_t *)nullptr, feat);
+    HIP_TRY(hipGetLastError());
+    const long long items = (long long)n * (kCells * HIVE_PLANES / 8);
+    dim3 grid((unsigned)((items + 255) / 256));
+#define HIVE_EXP_CASE(DT, LY)                                                                                  \
+    if (dtype == DT && layout == LY)                                                                           \
+        hipLaunchKernelGGL((hive_expand_kernel<DT, LY>), grid, dim3(256), 0, stream, boards, hist, feat, n, planes);
+    HIVE_EXP_CASE(0, 0) HIVE_EXP_CASE(0, 1) HIVE_EXP_CASE(1, 0) HIVE_EXP_CASE(1, 1) HIVE_EXP_CASE(2, 0) HIVE_EXP_CASE(2, 1)
+#undef HIVE_EXP_CASE
     HIP_TRY(hipGetLastError());
     return HIVE_OK;
 }
 
 int hive_movegen_launch(const HiveBoard *boards, int n, uint32_t *mask, int32_t *count, int16_t *list, void *stream)
 {
-    return launch_env(boards, nullptr, n, mask, count, list, nullptr, 0, 0, (hipStream_t)stream);
+    return launch_pieces(boards, n, mask, count, list, (hipStream_t)stream);
 }
 
 int hive_encode_launch(const HiveBoard *boards, const HiveHistory *hist, int n, void *planes, HiveDType dtype,
-                       HiveLayout layout, void *stream)
+                       HiveLayout layout, void *workspace, void *stream)
 {
-    if (planes == nullptr) return fail(HIVE_E_ARG, "hive_encode_launch: planes == NULL");
-    return launch_env(boards, hist, n, nullptr, nullptr, nullptr, planes, (int)dtype, (int)layout, (hipStream_t)stream);
+    return launch_encode(boards, hist, n, planes, (int)dtype, (int)layout, (unsigned long long *)workspace,
+                         (hipStream_t)stream);
 }
 
 int hive_batch_create(int n, int device, HiveBatch **out)
@@ -714,6 +762,7 @@ int hive_batch_create(int n, int device, HiveBatch **out)
     HIP_TRY(hipMalloc(&h->legal, sizeof(uint32_t) * HIVE_MASK_WORDS * (size_t)n));
     HIP_TRY(hipMalloc(&h->legal_count, sizeof(int32_t) * (size_t)n));
     HIP_TRY(hipMalloc(&h->legal_list, sizeof(int16_t) * HIVE_LIST_CAP * (size_t)n));
+    HIP_TRY(hipMalloc(&h->feat, sizeof(unsigned long long) * kCells * (size_t)n));
     HIP_TRY(hipMalloc(&h->illegal, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(h->illegal, 0, sizeof(unsigned long long)));
     *out = h;
@@ -729,6 +778,7 @@ int hive_batch_destroy(HiveBatch *h)
     (void)hipFree(h->legal);
     (void)hipFree(h->legal_count);
     (void)hipFree(h->legal_list);
+    (void)hipFree(h->feat);
     (void)hipFree(h->illegal);
     delete h;
     return HIVE_OK;
@@ -759,7 +809,7 @@ int hive_batch_reset(HiveBatch *h, const int32_t *idx, int k)
 static int ensure_legal(HiveBatch *h)
 {
     if (h->legal_valid) return HIVE_OK;
-    int rc = launch_env(h->boards, nullptr, h->n, h->legal, h->legal_count, h->legal_list, nullptr, 0, 0, h->stream);
+    int rc = launch_pieces(h->boards, h->n, h->legal, h->legal_count, h->legal_list, h->stream);
     if (rc == HIVE_OK) h->legal_valid = true;
     return rc;
 }
@@ -817,7 +867,7 @@ int hive_batch_encode(HiveBatch *h, void *planes, HiveDType dtype, HiveLayout la
 {
     if (!h || !planes) return fail(HIVE_E_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    return launch_env(h->boards, h->hist, h->n, nullptr, nullptr, nullptr, planes, (int)dtype, (int)layout, h->stream);
+    return launch_encode(h->boards, h->hist, h->n, planes, (int)dtype, (int)layout, h->feat, h->stream);
 }
 
 int hive_batch_terminal(HiveBatch *h, int8_t *over, int8_t *winner)

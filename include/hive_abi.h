@@ -106,8 +106,9 @@ int hive_batch_illegal_count(HiveBatch *h, int64_t *count /* host */);
 /* GamePlay.actions (env_hive.py:182-183, 196-304): legal set of the side to move.
  * mask  = device uint32[n][HIVE_MASK_WORDS], bit a = action a legal (may be NULL);
  * count = device int32[n] (may be NULL);
- * list  = device int16[n][HIVE_LIST_CAP], ascending action ids, -1 padded (may be NULL);
- *         a board with more than HIVE_LIST_CAP legal ids keeps the first HIVE_LIST_CAP. */
+ * list  = device int16[n][HIVE_LIST_CAP], ascending action ids, -1 padded (may be NULL; in the
+ *         stateless launch it needs mask != NULL); a board with more than HIVE_LIST_CAP legal
+ *         ids keeps the first HIVE_LIST_CAP. */
 int hive_batch_legal(HiveBatch *h, uint32_t *mask, int32_t *count, int16_t *list);
 
 /* GamePlay.encode_board (env_hive.py:306-485): the 56 planes from the mover's side. */
@@ -126,8 +127,9 @@ int hive_batch_import(HiveBatch *h, const HiveBoard *boards, const HiveHistory *
  * positions live in node pools).  Same semantics as the batch calls above. */
 int hive_movegen_launch(const HiveBoard *boards, int n, uint32_t *mask, int32_t *count,
                         int16_t *list, void *stream);
+/* workspace = device scratch of n * HIVE_CELLS * 8 bytes (the packed 56-bit-per-cell features). */
 int hive_encode_launch(const HiveBoard *boards, const HiveHistory *hist, int n, void *planes,
-                       HiveDType dtype, HiveLayout layout, void *stream);
+                       HiveDType dtype, HiveLayout layout, void *workspace, void *stream);
 
 #ifdef __cplusplus
 }
