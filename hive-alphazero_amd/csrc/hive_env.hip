@@ -121,22 +121,23 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
 
     // ---- one-hive test (move_checker.py:58-83 / env_hive.py:509-530): flood the hive without
     // the mover from one of its neighbours until every neighbour is reached or nothing grows.
+    // The piece's own flood (Ant reach, Grasshopper line flood, Spider first steps) runs in the
+    // SAME loop, speculatively for every top piece: two independent dependency chains per
+    // iteration, and the trip count is the max of the two floods instead of their sum.
     BB target = bb_and(nsrc, occp);
     const bool has_nb = bb_any(target);
     bool pinned = on_top && !stacked && !has_nb;    // lone piece: empty board => False
     bool act = on_top && !stacked && has_nb;
     BB reach = bb_lowest(target);
-    while (__any(act)) {
-        if (act) {
-            BB nx = bb_or(reach, bb_and(bb_neighbours(reach), occp));
-            bool covered = !bb_any(bb_andn(target, nx));
-            bool fixed = bb_eq(nx, reach);
-            reach = nx;
-            if (covered) act = false;
-            else if (fixed) { act = false; pinned = true; }
-        }
+#define HIVE_FLOOD_STEP()                                                                 \
+    if (act) {                                                                            \
+        BB nx = bb_or(reach, bb_and(bb_neighbours(reach), occp));                         \
+        bool covered = !bb_any(bb_andn(target, nx));                                      \
+        bool fixed = bb_eq(nx, reach);                                                    \
+        reach = nx;                                                                       \
+        if (covered) act = false;                                                         \
+        else if (fixed) { act = false; pinned = true; }                                   \
     }
-    const bool movable = on_top && !pinned;
 
     // ---- piece rule (pieces.py) on the board with the mover lifted
     BB rule = bb_zero();
@@ -145,8 +146,9 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
         BB L = bb_load(d_tables.line[on_board ? c : 0u]);
         BB Lo = bb_and(L, occ);
         BB V = srcbit;
-        bool ga = movable;
-        while (__any(ga)) {
+        bool ga = on_top;
+        while (__any(ga || act)) {
+            HIVE_FLOOD_STEP()
             if (ga) {
                 BB nx = bb_or(V, bb_and(bb_neighbours(V), Lo));
                 if (bb_eq(nx, V)) ga = false;
@@ -159,11 +161,13 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
         occupancy_views(occp, S);
         SlideCtx ctx = make_slide_ctx(occp, S);
         if (type == T_QUEEN) {
+            while (__any(act)) { HIVE_FLOOD_STEP() }
             rule = slide_step(ctx, srcbit);                       // pieces.py:35-44
         } else if (type == T_ANT) {
             BB R = srcbit;                                        // pieces.py:59-63, move_checker.py:217-246
-            bool aa = movable;
-            while (__any(aa)) {
+            bool aa = on_top;
+            while (__any(aa || act)) {
+                HIVE_FLOOD_STEP()
                 if (aa) {
                     BB nx = bb_or(R, slide_step(ctx, R));
                     if (bb_eq(nx, R)) aa = false;
@@ -180,8 +184,9 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 // For each first step a: {c} = slide(slide(a) \ src) \ {src, a}; c != b holds by itself.
                 BB A = slide_step(ctx, srcbit);
                 BB acc = bb_zero();
-                bool sa = movable && bb_any(A);
-                while (__any(sa)) {
+                bool sa = on_top && bb_any(A);
+                while (__any(sa || act)) {
+                    HIVE_FLOOD_STEP()
                     if (sa) {
                         BB a = bb_lowest(A);
                         A = bb_andn(A, a);
@@ -196,6 +201,7 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 rule = bb_andn(acc, veto);
             } else {
                 // Beetle, pieces.py:100-113 + move_checker.py:201-209
+                while (__any(act)) { HIVE_FLOOD_STEP() }
                 BB Q1 = slide_raw(ctx, srcbit);
                 BB Q0 = shift_dirs(bb_andn(bb_andn(srcbit, ctx.cs[0]), b0), bb_andn(bb_andn(srcbit, ctx.cs[1]), b1),
                                    bb_andn(bb_andn(srcbit, ctx.cs[2]), b2), bb_andn(bb_andn(srcbit, ctx.cs[3]), b3),
@@ -205,6 +211,8 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
             }
         }
     }
+#undef HIVE_FLOOD_STEP
+    const bool movable = on_top && !pinned;
 
     // ---- next_move_tiles (env_hive.py:66-69,150-161)
     const BB empty_adj = bb_andn(nocc, occ);
@@ -221,13 +229,10 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     if (valid && in_hand) {
         if (own) {
             // only the first in-hand piece of each type emits placements (env_hive.py:218-219)
-            bool first = true;
             const int g0 = slot_group_start(slot);
-            HIVE_UNROLL for (int r = 0; r < 22; ++r) {
-                int rs = r >= 11 ? r - 11 : r, rc = r >= 11 ? 1 : 0;
-                bool earlier_same = rc == color && rs >= g0 && rs < slot;
-                if (earlier_same && ((pw[r >> 2] >> ((r & 3) * 8)) & 0xFFu) >= (unsigned)kCells) first = false;
-            }
+            bool first = true;      // every earlier slot of the same type is already on the board
+            if (slot > g0) first = state_byte(st, (unsigned)(color * 11 + g0)) < (unsigned)kCells;
+            if (slot > g0 + 1) first = first && state_byte(st, (unsigned)(color * 11 + g0 + 1)) < (unsigned)kCells;
             if (first) {
                 BB base = bb_andn(nmt, occ);
                 if (turn == 1u) D = bb_and(base, bb_bit((unsigned)kStartCell));
