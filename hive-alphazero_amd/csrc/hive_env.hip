@@ -630,19 +630,23 @@ __global__ void hive_terminal_kernel(const HiveBoard *__restrict__ boards, int n
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n) return;
-    const HiveBoard *B = &boards[b];
+    const uint4 *rec = reinterpret_cast<const uint4 *>(&boards[b]);
+    uint4 r0 = rec[0], r1 = rec[1];
+    const uint32_t pw[6] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y};      // pos[0..23] (22 used)
     bool surrounded[2] = {false, false};
-    for (int col = 0; col < 2; ++col) {
-        unsigned c = B->pos[col * 11];
-        if (c >= (unsigned)kCells) continue;
-        int cnt = 0;
-        for (int i = 0; i < 6; ++i) {
-            unsigned adj = d_tables.nbr[c][i];
-            bool occd = false;
-            for (int r = 0; r < 22; ++r) occd = occd || (B->pos[r] == adj);
-            cnt += occd ? 1 : 0;
+    HIVE_UNROLL for (int col = 0; col < 2; ++col) {
+        unsigned c = col == 0 ? (pw[0] & 0xFFu) : (pw[2] >> 24);
+        if (c < (unsigned)kCells) {
+            const uint2 nb = *reinterpret_cast<const uint2 *>(d_tables.nbr[c]);
+            int cnt = 0;
+            HIVE_UNROLL for (int i = 0; i < 6; ++i) {
+                unsigned adj = ((i < 4 ? nb.x : nb.y) >> ((i & 3) * 8)) & 0xFFu;
+                bool occd = false;
+                HIVE_UNROLL for (int r = 0; r < 22; ++r) occd = occd || (((pw[r >> 2] >> ((r & 3) * 8)) & 0xFFu) == adj);
+                cnt += occd ? 1 : 0;
+            }
+            surrounded[col] = cnt == 6;
         }
-        surrounded[col] = cnt == 6;
     }
     bool ov = surrounded[0] || surrounded[1];
     int w = 0;
