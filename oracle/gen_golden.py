@@ -207,6 +207,70 @@ def cmd_games(a):
     print(name, "games", len(games), "positions", npos)
 
 
+def stub_predict(planes):
+    """Deterministic stand-in for the network: (p[1584] float32, v float) as a pure function of the
+    planes.  Uses its own RandomState so the global numpy stream (Dirichlet noise, final choice)
+    is consumed only by the search itself.  tests/mcts_stub.py holds the identical function."""
+    import zlib
+    h = zlib.crc32(np.ascontiguousarray(planes, dtype=np.float32).tobytes())
+    rs = np.random.RandomState(h)
+    p = rs.dirichlet(np.full(1584, 0.5)).astype(np.float32)
+    v = float(rs.uniform(-1.0, 1.0))
+    return p, v
+
+
+class StubPipe:
+    def send(self, x):
+        self._x = x
+
+    def recv(self):
+        return stub_predict(self._x)
+
+
+def cmd_mcts(a):
+    """HivePlayer (woker/solo_play.py) at SEARCH_THREADS=1, seeded numpy, stub evaluator."""
+    import contextlib
+    import io
+    import woker.solo_play as sp
+    sp.SEARCH_THREADS = 1
+    cases = []
+    for ci, (pre_plies, seed) in enumerate([(0, 11), (1, 12), (4, 13), (9, 14), (16, 15), (27, 16)]):
+        rng = np.random.default_rng(100 + ci)
+        g = _new_game()
+        prefix = []
+        for _ in range(pre_plies):
+            act = choose(g, rng, "uniform")
+            prefix.append(act)
+            g.move(act)
+        player = sp.HivePlayer(pipes=[StubPipe()])
+        player.simulation_num_per_move = a.sims
+        np.random.seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            action, (policy, sum_all) = player.action(g)
+        root = player.tree[g.state_key]
+        edges = [[int(k), int(v.n), float(v.w), float(v.p)] for k, v in root.a.items()]
+        cases.append({"prefix": prefix, "seed": seed, "sims": a.sims, "turn": int(g.state.turn),
+                      "action": int(action), "sum_all": float(sum_all),
+                      "policy_nz": [[i, float(x)] for i, x in enumerate(policy) if x != 0],
+                      "root_edges": edges, "tree_size": len(player.tree)})
+        print("case", ci, "turn", g.state.turn, "action", action, "tree", len(player.tree), flush=True)
+    # a short self-play segment: four consecutive searched plies from one seed
+    g = _new_game()
+    np.random.seed(99)
+    seq = []
+    players = [sp.HivePlayer(pipes=[StubPipe()]), sp.HivePlayer(pipes=[StubPipe()])]
+    for ply in range(4):
+        pl = players[g.state.player()]
+        pl.simulation_num_per_move = a.sims
+        with contextlib.redirect_stdout(io.StringIO()):
+            action, (policy, sum_all) = pl.action(g)
+        seq.append({"action": int(action), "sum_all": float(sum_all)})
+        g.move(action)
+    with gzip.open(os.path.join(GOLD, "mcts.json.gz"), "wt", compresslevel=9) as f:
+        json.dump({"cases": cases, "segment": {"seed": 99, "sims": a.sims, "plies": seq}}, f, separators=(",", ":"))
+    print("mcts.json.gz written")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -217,5 +281,7 @@ if __name__ == "__main__":
     pg.add_argument("--seed0", type=int, default=0)
     pg.add_argument("--no-planes", action="store_true")
     pg.add_argument("--out", default=None)
+    pm = sub.add_parser("mcts")
+    pm.add_argument("--sims", type=int, default=50)
     a = ap.parse_args()
-    {"tables": cmd_tables, "games": cmd_games}[a.cmd](a)
+    {"tables": cmd_tables, "games": cmd_games, "mcts": cmd_mcts}[a.cmd](a)

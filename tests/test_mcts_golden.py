@@ -1,0 +1,101 @@
+"""HivePlayer (the mirror of woker/solo_play.py) against the reference's own search: seeded numpy,
+SEARCH_THREADS = 1, stub evaluator -- visit counts, W, priors, policy and chosen action must be
+identical.  CPU variant drives the search with the oracle env (config C1); the GPU variant with
+the HIP-backed GamePlay façade."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from mcts_stub import StubPipe
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mcts.json.gz")
+
+
+def _load():
+    with gzip.open(GOLD, "rt") as f:
+        return json.load(f)
+
+
+def _run_cases(make_env, ncases=None):
+    import hive_alphazero_amd.solo_play as sp
+    sp.SEARCH_THREADS = 1
+    data = _load()
+    for case in data["cases"][:ncases]:
+        g = make_env()
+        for a in case["prefix"]:
+            g.move(a)
+        assert g.state.turn == case["turn"]
+        player = sp.HivePlayer(pipes=[StubPipe()])
+        player.simulation_num_per_move = case["sims"]
+        np.random.seed(case["seed"])
+        action, (policy, sum_all) = player.action(g)
+        root = player.tree[g.state_key]
+        edges = [[int(k), int(v.n), float(v.w), float(v.p)] for k, v in root.a.items()]
+        assert edges == case["root_edges"], f"turn {case['turn']}"
+        assert action == case["action"]
+        assert float(sum_all) == case["sum_all"]
+        assert [[i, float(x)] for i, x in enumerate(policy) if x != 0] == case["policy_nz"]
+        assert len(player.tree) == case["tree_size"]
+    return data
+
+
+def test_hiveplayer_matches_reference_cpu_oracle_env():
+    from oracle_env import OracleGamePlay
+    data = _run_cases(OracleGamePlay)
+    # the four-ply searched segment (two players, one numpy stream)
+    import hive_alphazero_amd.solo_play as sp
+    seg = data["segment"]
+    g = OracleGamePlay()
+    np.random.seed(seg["seed"])
+    players = [sp.HivePlayer(pipes=[StubPipe()]), sp.HivePlayer(pipes=[StubPipe()])]
+    for rec in seg["plies"]:
+        pl = players[g.state.player()]
+        pl.simulation_num_per_move = seg["sims"]
+        action, (policy, sum_all) = pl.action(g)
+        assert action == rec["action"] and float(sum_all) == rec["sum_all"]
+        g.move(action)
+
+
+@pytest.mark.gpu
+def test_hiveplayer_matches_reference_gpu_env():
+    import torch
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.env_hive import GamePlay
+    _run_cases(lambda: GamePlay(1050, 900), ncases=4)
+
+
+@pytest.mark.gpu
+def test_gameplay_facade_matches_golden_game(golden_games):
+    """The single-game drop-in API (GamePlay) replayed over one golden game: actions(), state_key,
+    encode_board(), game_is_over()/winner, deepcopy independence."""
+    import copy
+    import torch
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.env_hive import GamePlay
+    from hive_alphazero_amd.config import PIECE_BLACK, PIECE_WHITE
+    for gm in (golden_games[0], next(g for g in golden_games if g["plies"][-1]["over"])):
+        g = GamePlay(1050, 900)
+        for i, rec in enumerate(gm["plies"]):
+            assert g.state.turn == rec["t"] and g.actions() == rec["legal"], i
+            assert g.state_key == rec["key"], i
+            assert g.game_is_over() == rec["over"]
+            if rec["over"]:
+                want = {0: None, 1: PIECE_WHITE, 2: PIECE_BLACK}[rec["win"]]
+                assert g.state.winner == want
+            pl = g.encode_board().copy()
+            assert pl.dtype == np.float64 and pl.shape == (12, 12, 56)
+            pl[:, :, 31] = 0
+            got = sorted(int((x * 12 + y) * 56 + p) for x, y, p in np.argwhere(pl != 0))
+            assert got == rec["planes"], i
+            if rec["a"] is None:
+                break
+            if i == 5:
+                c = copy.deepcopy(g)
+                c.move(rec["a"])
+                assert g.state.turn == rec["t"] and c.state.turn == rec["t"] + 1
+            g.move(rec["a"])
+    key, core = g.decode_action(858)
+    assert key == "<class 'pieces.Queen'>0" and core == ("N", "13")
