@@ -1,0 +1,215 @@
+"""ChessNet: mirror of the reference's alpha_zero/alpha_net.py (:25-95) + an MI355X inference engine.
+
+`ChessNet` keeps the reference's module names, construction order (so torch.manual_seed(k)
+yields the same initial tensors) and forward arithmetic, hence the same 255 state_dict keys:
+checkpoints ({'state_dict': ...}, alpha_zero/train.py:35-51) load both ways.
+
+`InferenceNet` is how leaf batches are evaluated on the GPU: eval-mode BatchNorm folded into the
+convolutions, bf16 (or fp16/fp32) weights, channels-last activations so the 3x3 convolutions
+run as NHWC implicit GEMMs on the MFMA units (MIOpen / hipBLASLt), softmax in fp32, and the
+whole forward captured in a HIP graph per batch size.  It consumes the planes exactly as the env
+kernels emit them ([B,12,12,56] channels-last), so there is no transpose between encode and
+conv1.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .config import LOSS_WEIGHT, MAX_MAP_FULL, STATE_FEATURES
+
+ACTIONS = MAX_MAP_FULL * MAX_MAP_FULL * 11
+
+
+class board_data(torch.utils.data.Dataset):            # alpha_net.py:14-23
+    def __init__(self, dataset):
+        self.X = dataset[:, 0]
+        self.y_p, self.y_v = dataset[:, 1], dataset[:, 2]
+
+    def __len__(self):
+        return len(self.X)
+
+    def __getitem__(self, idx):
+        return self.X[idx].transpose(2, 0, 1), self.y_p[idx], self.y_v[idx]
+
+
+class ConvBlock(nn.Module):                             # alpha_net.py:25-34
+    def __init__(self):
+        super().__init__()
+        self.action_size = ACTIONS
+        self.conv1 = nn.Conv2d(STATE_FEATURES, 256, 3, stride=1, padding=1)
+        self.bn1 = nn.BatchNorm2d(256)
+
+    def forward(self, s):
+        return F.relu(self.bn1(self.conv1(s)))
+
+
+class ResBlock(nn.Module):                              # alpha_net.py:36-54
+    def __init__(self, inplanes=256, planes=256, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+
+    def forward(self, x):
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        out = out + x
+        return F.relu(out)
+
+
+class OutBlock(nn.Module):                              # alpha_net.py:56-80
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(256, 1, kernel_size=1)                    # value head
+        self.bn = nn.BatchNorm2d(1)
+        self.fc1 = nn.Linear(MAX_MAP_FULL * MAX_MAP_FULL, 64)
+        self.fc2 = nn.Linear(64, 1)
+        self.conv1 = nn.Conv2d(256, 128, kernel_size=1)                 # policy head
+        self.bn1 = nn.BatchNorm2d(128)
+        self.logsoftmax = nn.LogSoftmax(dim=1)
+        self.fc = nn.Linear(MAX_MAP_FULL * MAX_MAP_FULL * 128, ACTIONS)
+
+    def forward(self, s):
+        v = F.relu(self.bn(self.conv(s)))
+        v = v.reshape(-1, MAX_MAP_FULL * MAX_MAP_FULL)
+        v = F.relu(self.fc1(v))
+        v = torch.tanh(self.fc2(v))
+        p = F.relu(self.bn1(self.conv1(s)))
+        p = p.reshape(-1, MAX_MAP_FULL * MAX_MAP_FULL * 128)
+        p = self.fc(p)
+        p = self.logsoftmax(p).exp()
+        return p, v
+
+
+class ChessNet(nn.Module):                              # alpha_net.py:82-95
+    def __init__(self):
+        super().__init__()
+        self.conv = ConvBlock()
+        for block in range(19):
+            setattr(self, "res_%i" % block, ResBlock())
+        self.outblock = OutBlock()
+
+    def forward(self, s):
+        s = self.conv(s)
+        for block in range(19):
+            s = getattr(self, "res_%i" % block)(s)
+        return self.outblock(s)
+
+
+class AlphaLoss(nn.Module):                             # alpha_net.py:98-115
+    def forward(self, y_value, value, y_policy, policy):
+        value_error = (value - y_value) ** 2
+        policy_error = torch.sum((-policy * (1e-6 + y_policy.float()).float().log()), 1)
+        return (value_error.view(-1).float() * LOSS_WEIGHT["value"] + policy_error * LOSS_WEIGHT["policy"]).mean()
+
+
+def train(net, dataset, epoch_start=0, epoch_stop=10, cpu=0, batch_size=512, lr=0.001, log=print):
+    """alpha_net.py:117-162 (Adam 1e-3, MultiStepLR [100,200,300,400] x0.2, AlphaLoss); the loss plot
+    is left to the caller.  Returns the per-epoch mean losses."""
+    torch.manual_seed(cpu)
+    dev = next(net.parameters()).device
+    net.train()
+    criterion = AlphaLoss()
+    optimizer = torch.optim.Adam(net.parameters(), lr=lr)
+    scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[100, 200, 300, 400], gamma=0.2)
+    loader = torch.utils.data.DataLoader(board_data(dataset), batch_size=batch_size, shuffle=True, num_workers=0)
+    losses_per_epoch = []
+    for epoch in range(epoch_start, epoch_stop):
+        total, nb = 0.0, 0
+        for state, policy, value in loader:
+            state, policy, value = state.to(dev).float(), policy.float().to(dev), value.to(dev).float()
+            optimizer.zero_grad()
+            policy_pred, value_pred = net(state)
+            loss = criterion(value_pred[:, 0], value, policy_pred, policy)
+            loss.backward()
+            optimizer.step()
+            total += loss.item()
+            nb += 1
+        scheduler.step()
+        losses_per_epoch.append(total / max(nb, 1))
+        log("epoch %d loss %.4f" % (epoch + 1, losses_per_epoch[-1]))
+        if len(losses_per_epoch) > 100 and \
+                abs(sum(losses_per_epoch[-4:-1]) / 3 - sum(losses_per_epoch[-16:-13]) / 3) <= 0.01:
+            break
+    return losses_per_epoch
+
+
+def _fold(conv, bn):
+    """eval-mode BatchNorm folded into the preceding convolution (fp32 math)."""
+    w = conv.weight.detach().float()
+    b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    return w * scale.view(-1, 1, 1, 1), bn.bias.detach().float() + (b - bn.running_mean.detach().float()) * scale
+
+
+class InferenceNet:
+    """Batched leaf evaluator for a ChessNet (eval mode).  __call__(planes_hwc) -> (p fp32 [B,1584], v fp32 [B])."""
+
+    def __init__(self, net, dtype=torch.bfloat16, device=None, use_graph=True):
+        dev = torch.device(device) if device is not None else next(net.parameters()).device
+        self.device, self.dtype, self.use_graph = dev, dtype, use_graph and dev.type == "cuda"
+        net = net.eval()
+        cl = torch.channels_last
+
+        def prep(w, b):
+            return (w.to(dev, dtype).contiguous(memory_format=cl), b.to(dev, dtype))
+
+        self.stem = prep(*_fold(net.conv.conv1, net.conv.bn1))
+        self.blocks = []
+        for i in range(19):
+            rb = getattr(net, "res_%i" % i)
+            self.blocks.append((prep(*_fold(rb.conv1, rb.bn1)), prep(*_fold(rb.conv2, rb.bn2))))
+        ob = net.outblock
+        self.vconv = prep(*_fold(ob.conv, ob.bn))
+        self.pconv = prep(*_fold(ob.conv1, ob.bn1))
+        # the policy FC consumes the head in NHWC order: permute its columns once (c*144+hw -> hw*128+c)
+        wfc = ob.fc.weight.detach().float().view(ACTIONS, 128, 144).permute(0, 2, 1).reshape(ACTIONS, 144 * 128)
+        self.fc = (wfc.to(dev, dtype).contiguous(), ob.fc.bias.detach().to(dev, dtype))
+        self.fc1 = (ob.fc1.weight.detach().to(dev, torch.float32), ob.fc1.bias.detach().to(dev, torch.float32))
+        self.fc2 = (ob.fc2.weight.detach().to(dev, torch.float32), ob.fc2.bias.detach().to(dev, torch.float32))
+        self._graphs = {}
+
+    def _forward(self, x_hwc):
+        # x_hwc: [B,12,12,56] in self.dtype; viewed as NCHW with channels-last strides (zero copy)
+        x = x_hwc.permute(0, 3, 1, 2)
+        s = F.relu(F.conv2d(x, self.stem[0], self.stem[1], padding=1))
+        for (w1, b1), (w2, b2) in self.blocks:
+            o = F.relu(F.conv2d(s, w1, b1, padding=1))
+            o = F.conv2d(o, w2, b2, padding=1)
+            s = F.relu(o + s)
+        B = s.shape[0]
+        v = F.relu(F.conv2d(s, self.vconv[0], self.vconv[1])).float().reshape(B, 144)
+        v = F.relu(F.linear(v, *self.fc1))
+        v = torch.tanh(F.linear(v, *self.fc2)).reshape(B)
+        p = F.relu(F.conv2d(s, self.pconv[0], self.pconv[1]))          # [B,128,12,12] channels-last
+        p = p.permute(0, 2, 3, 1).reshape(B, 144 * 128)                # NHWC flatten (matches self.fc columns)
+        p = F.linear(p, *self.fc).float()
+        return torch.softmax(p, dim=1), v
+
+    @torch.no_grad()
+    def __call__(self, planes_hwc):
+        B = planes_hwc.shape[0]
+        if planes_hwc.dtype != self.dtype:
+            planes_hwc = planes_hwc.to(self.dtype)
+        if not self.use_graph:
+            return self._forward(planes_hwc)
+        g = self._graphs.get(B)
+        if g is None:
+            static_in = torch.zeros_like(planes_hwc)
+            static_in.copy_(planes_hwc)
+            s = torch.cuda.Stream(self.device)
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    self._forward(static_in)
+            torch.cuda.current_stream(self.device).wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._forward(static_in)
+            g = (graph, static_in, out)
+            self._graphs[B] = g
+        graph, static_in, out = g
+        static_in.copy_(planes_hwc)
+        graph.replay()
+        return out

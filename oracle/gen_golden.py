@@ -271,6 +271,48 @@ def cmd_mcts(a):
     print("mcts.json.gz written")
 
 
+def cmd_net(a):
+    """alpha_zero/alpha_net.py::ChessNet: (1) same-seed init of the build's ChessNet gives identical
+    tensors, (2) outputs of the reference net on planes of golden positions (CPU fp32)."""
+    import torch
+    sys.path.insert(0, REPO)
+    from alpha_zero.alpha_net import ChessNet as RefNet
+    from hive_alphazero_amd.alpha_net import ChessNet as MyNet
+    torch.manual_seed(a.seed)
+    ref = RefNet().eval()
+    torch.manual_seed(a.seed)
+    mine = MyNet().eval()
+    sd_r, sd_m = ref.state_dict(), mine.state_dict()
+    assert list(sd_r.keys()) == list(sd_m.keys()), "state_dict keys differ"
+    for k in sd_r:
+        assert torch.equal(sd_r[k], sd_m[k]), k
+    mine.load_state_dict(sd_r)          # checkpoint compatibility (train.py:35-38)
+    with gzip.open(os.path.join(GOLD, "games_full.json.gz"), "rt") as f:
+        games = json.load(f)["games"]
+    picks = [(0, 10), (0, 31), (1, 20), (2, 45)]
+    xs = []
+    for gi, ply in picks:
+        rec = games[gi]["plies"][ply]
+        pl = np.zeros((12, 12, 56), dtype=np.float32)
+        pl.reshape(-1)[rec["planes"]] = 1.0
+        pl[:, :, 31] = rec["t"]
+        xs.append(pl.transpose(2, 0, 1))
+    x = torch.from_numpy(np.ascontiguousarray(np.stack(xs))).contiguous()
+    with torch.no_grad():
+        p_r, v_r = ref(x)
+        p_m, v_m = mine(x)
+    assert torch.allclose(p_r, p_m, atol=1e-7) and torch.allclose(v_r, v_m, atol=1e-6)
+    out = {"seed": a.seed, "picks": picks, "n_keys": len(sd_r), "n_params": int(sum(v.numel() for v in ref.parameters())),
+           "v": [float(t) for t in v_r.view(-1)],
+           "p_top": [[[int(i), float(p_r[b, i])] for i in torch.topk(p_r[b], 8).indices] for b in range(len(picks))],
+           "p_first16": [[float(t) for t in p_r[b, :16]] for b in range(len(picks))],
+           "p_sum": [float(p_r[b].sum()) for b in range(len(picks))],
+           "torch": torch.__version__}
+    with open(os.path.join(GOLD, "net.json"), "w") as f:
+        json.dump(out, f)
+    print("net.json written", out["v"])
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -283,5 +325,7 @@ if __name__ == "__main__":
     pg.add_argument("--out", default=None)
     pm = sub.add_parser("mcts")
     pm.add_argument("--sims", type=int, default=50)
+    pn = sub.add_parser("net")
+    pn.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
-    {"tables": cmd_tables, "games": cmd_games, "mcts": cmd_mcts}[a.cmd](a)
+    {"tables": cmd_tables, "games": cmd_games, "mcts": cmd_mcts, "net": cmd_net}[a.cmd](a)

@@ -1,0 +1,83 @@
+"""ChessNet mirror + InferenceNet against outputs of the reference's alpha_zero/alpha_net.py
+(tests/golden/net.json, produced by oracle/gen_golden.py net, which also asserted that a same-seed
+init gives identical tensors to the reference and that the state_dict keys are the same 255)."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _inputs(gold):
+    with gzip.open(os.path.join(GOLD, "games_full.json.gz"), "rt") as f:
+        games = json.load(f)["games"]
+    xs = []
+    for gi, ply in gold["picks"]:
+        rec = games[gi]["plies"][ply]
+        pl = np.zeros((12, 12, 56), dtype=np.float32)
+        pl.reshape(-1)[rec["planes"]] = 1.0
+        pl[:, :, 31] = rec["t"]
+        xs.append(pl)
+    return torch.from_numpy(np.stack(xs))          # [B,12,12,56] (HWC, the env's layout)
+
+
+def _gold():
+    with open(os.path.join(GOLD, "net.json")) as f:
+        return json.load(f)
+
+
+def _check(p, v, gold, atol_p, atol_v):
+    p, v = p.float().cpu(), v.float().cpu().view(-1)
+    assert np.allclose(v.numpy(), gold["v"], atol=atol_v)
+    for b, top in enumerate(gold["p_top"]):
+        for i, val in top:
+            assert abs(float(p[b, i]) - val) <= atol_p
+        assert np.allclose(p[b, :16].numpy(), gold["p_first16"][b], atol=atol_p)
+        assert abs(float(p[b].sum()) - 1.0) < 1e-3
+
+
+def test_chessnet_matches_reference_cpu_fp32():
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    gold = _gold()
+    torch.manual_seed(gold["seed"])
+    net = ChessNet().eval()
+    sd = net.state_dict()
+    assert len(sd) == gold["n_keys"] == 255
+    assert sum(p.numel() for p in net.parameters()) == gold["n_params"] == 51803188
+    for k in ("conv.conv1.weight", "conv.bn1.running_mean", "res_0.conv1.weight", "res_18.bn2.num_batches_tracked",
+              "outblock.conv.weight", "outblock.bn.weight", "outblock.fc1.bias", "outblock.fc2.weight",
+              "outblock.conv1.bias", "outblock.bn1.running_var", "outblock.fc.weight"):
+        assert k in sd
+    x = _inputs(gold)
+    with torch.no_grad():
+        p, v = net(x.permute(0, 3, 1, 2))
+    _check(p, v, gold, 1e-6, 1e-5)          # tolerance: fp32 same-op replay
+    inf = InferenceNet(net, dtype=torch.float32, device="cpu", use_graph=False)
+    p2, v2 = inf(x)
+    _check(p2, v2, gold, 1e-6, 1e-5)        # BN folding + NHWC head permutation are exact up to fp32 rounding
+    # checkpoint round trip with the reference's container format (train.py:35-38,50-51)
+    net2 = ChessNet()
+    net2.load_state_dict({"state_dict": sd}["state_dict"])
+
+
+@pytest.mark.gpu
+def test_inference_net_gpu_tolerances():
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    gold = _gold()
+    torch.manual_seed(gold["seed"])
+    net = ChessNet().eval()
+    x = _inputs(gold).cuda()
+    with torch.no_grad():
+        p, v = net.cuda()(x.permute(0, 3, 1, 2))
+    _check(p, v, gold, 2e-6, 2e-5)                              # fp32 on the GPU
+    for dt, atol_p, atol_v in ((torch.float32, 2e-6, 2e-5), (torch.bfloat16, 2e-4, 3e-2), (torch.float16, 5e-5, 5e-3)):
+        inf = InferenceNet(net, dtype=dt)
+        p2, v2 = inf(x)
+        _check(p2, v2, gold, atol_p, atol_v)                    # stated tolerance of the reduced-precision engine
+        p3, v3 = inf(x)                                         # graph replay is deterministic
+        assert torch.equal(p2, p3) and torch.equal(v2, v3)
