@@ -30,6 +30,11 @@ ABI_SYMBOLS = [
     "hive_batch_size", "hive_batch_set_stream", "hive_batch_reset", "hive_batch_step",
     "hive_batch_illegal_count", "hive_batch_legal", "hive_batch_encode", "hive_batch_terminal",
     "hive_batch_export", "hive_batch_import", "hive_movegen_launch", "hive_encode_launch",
+    "hive_terminal_launch", "hive_step_launch", "hive_leaf_launch",
+    # include/hive_search.h
+    "hive_search_create", "hive_search_destroy", "hive_search_set_stream", "hive_search_set_params",
+    "hive_search_set_roots", "hive_search_select", "hive_search_backup", "hive_search_policy",
+    "hive_search_node_counts",
 ]
 
 
@@ -80,6 +85,18 @@ def load():
     L.hive_movegen_launch.argtypes = [vp, i32, vp, vp, vp, vp]
     L.hive_encode_launch.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.hive_debug_tables.argtypes = [vp, vp, vp]
+    L.hive_terminal_launch.argtypes = [vp, i32, vp, vp, vp]
+    L.hive_step_launch.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.hive_leaf_launch.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.hive_search_create.argtypes = [i32, i32, i32, i32, ctypes.c_uint64, ctypes.POINTER(vp)]
+    L.hive_search_destroy.argtypes = [vp]
+    L.hive_search_set_stream.argtypes = [vp, vp]
+    L.hive_search_set_params.argtypes = [vp, vp]
+    L.hive_search_set_roots.argtypes = [vp, vp, vp, vp]
+    L.hive_search_select.argtypes = [vp, i32, vp, vp]
+    L.hive_search_backup.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.hive_search_policy.argtypes = [vp, vp, vp, vp, i32]
+    L.hive_search_node_counts.argtypes = [vp, vp]
     for name in ABI_SYMBOLS:
         getattr(L, name)
     _lib = L

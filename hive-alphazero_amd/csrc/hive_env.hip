@@ -24,6 +24,7 @@
 #include "../../include/hive_abi.h"
 #include "hive_bb.hpp"
 #include "hive_tables.hpp"
+#include "hive_step.hpp"
 
 namespace hive {
 
@@ -542,13 +543,6 @@ hive_expand_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__re
 }
 
 // ------------------------------------------------------------------ step / reset / terminal
-__device__ __forceinline__ void set_cell_bit(uint32_t w[6], unsigned cell)
-{
-    unsigned wi, bit;
-    cell_word_bit(cell, wi, bit);
-    HIVE_UNROLL for (int i = 0; i < 6; ++i) w[i] |= (wi == (unsigned)i) ? (1u << bit) : 0u;
-}
-
 // GamePlay.move (env_hive.py:99-171); one lane per board.
 __global__ void hive_step_kernel(HiveBoard *__restrict__ boards, HiveHistory *__restrict__ hist, int n,
                                  const int32_t *__restrict__ actions, const uint32_t *__restrict__ legal_mask,
@@ -558,52 +552,12 @@ __global__ void hive_step_kernel(HiveBoard *__restrict__ boards, HiveHistory *__
     if (b >= n) return;
     int a = actions[b];
     if (a == -2) return;
-    HiveBoard *B = &boards[b];
-    unsigned turn = B->turn, flags = B->flags, hl = B->hist_len;
-    const int stm = (turn & 1u) ? 0 : 1;
-    if (a < -2 || a >= HIVE_ACTIONS) { atomicAdd(illegal_count, 1ull); return; }
+    if (a < -2 || a >= HIVE_ACTIONS) { if (illegal_count) atomicAdd(illegal_count, 1ull); return; }
     if (a >= 0 && legal_mask != nullptr) {
         uint32_t wmask = legal_mask[(long long)b * HIVE_MASK_WORDS + (a >> 5)];
-        if (!((wmask >> (a & 31)) & 1u)) { atomicAdd(illegal_count, 1ull); return; }
+        if (!((wmask >> (a & 31)) & 1u)) { if (illegal_count) atomicAdd(illegal_count, 1ull); return; }
     }
-    // the planes of the position we are leaving inserted it into its perspective's history
-    // (env_hive.py:436-445); apply that insertion now, before the board changes
-    if ((flags & 4u) && hist != nullptr) {
-        uint32_t ownm[6] = {0, 0, 0, 0, 0, 0}, enm[6] = {0, 0, 0, 0, 0, 0};
-        for (int r = 0; r < 22; ++r) {
-            unsigned c = B->pos[r];
-            if (c < (unsigned)kCells) {
-                if ((r >= 11 ? 1 : 0) == stm) set_cell_bit(ownm, c);
-                else set_cell_bit(enm, c);
-            }
-        }
-        HiveHistory *H = &hist[b];
-        for (int age = 3; age > 0; --age)
-            for (int k = 0; k < 2; ++k)
-                for (int w = 0; w < 6; ++w) H->m[stm][age][k][w] = H->m[stm][age - 1][k][w];
-        for (int w = 0; w < 6; ++w) { H->m[stm][0][0][w] = ownm[w]; H->m[stm][0][1][w] = enm[w]; }
-        unsigned len = stm == 0 ? (hl & 15u) : (hl >> 4);
-        len = len < 4u ? len + 1u : 4u;
-        hl = stm == 0 ? ((hl & 0xF0u) | len) : ((hl & 0x0Fu) | (len << 4));
-    }
-    if (a == -1) {
-        // pass (env_hive.py:100-103) and skip_turn (:493-496): next_move_tiles are not rebuilt
-        B->turn = (uint8_t)(turn + 1u);
-        B->flags = (uint8_t)(flags & 3u);
-        B->hist_len = (uint8_t)hl;
-        return;
-    }
-    const unsigned cell = (unsigned)a / 11u, slot = (unsigned)a - cell * 11u;
-    const unsigned q = (unsigned)stm * 11u + slot;
-    unsigned h = 0;
-    for (int r = 0; r < 22; ++r) h += (B->pos[r] == cell && (unsigned)r != q) ? 1u : 0u;   // len(end_tile.pieces), :119,125
-    B->pos[q] = (uint8_t)cell;
-    uint8_t lb = B->lvl[q >> 1];
-    B->lvl[q >> 1] = (q & 1u) ? (uint8_t)((lb & 0x0Fu) | (h << 4)) : (uint8_t)((lb & 0xF0u) | h);
-    turn += 1u;
-    B->turn = (uint8_t)turn;
-    B->flags = (uint8_t)((turn == 2u ? 2u : 0u) | 4u);
-    B->hist_len = (uint8_t)hl;
+    apply_action(&boards[b], hist ? &hist[b] : nullptr, a);
 }
 
 __global__ void hive_reset_kernel(HiveBoard *__restrict__ boards, HiveHistory *__restrict__ hist, int n,
@@ -675,6 +629,9 @@ static int fail(int code, const std::string &msg)
     g_err = msg;
     return code;
 }
+namespace hive {
+int set_error(int code, const std::string &msg) { return fail(code, msg); }
+}
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
@@ -725,13 +682,13 @@ static int launch_pieces(const HiveBoard *boards, int n, uint32_t *mask, int32_t
 }
 
 static int launch_encode(const HiveBoard *boards, const HiveHistory *hist, int n, void *planes, int dtype, int layout,
-                         unsigned long long *feat, hipStream_t stream)
+                         unsigned long long *feat, hipStream_t stream, uint32_t *mask = nullptr, int32_t *count = nullptr)
 {
     if (n <= 0 || boards == nullptr || planes == nullptr || feat == nullptr)
         return fail(HIVE_E_ARG, "encode: n <= 0 or a NULL buffer");
     if (dtype < 0 || dtype > 2 || layout < 0 || layout > 1) return fail(HIVE_E_ARG, "encode: unknown dtype/layout");
     hipLaunchKernelGGL((hive_piece_kernel<true>), dim3((unsigned)((n + 7) / 8)), dim3(NW * 64), 0, stream, boards, n,
-                       (uint32_t *)nullptr, (int32_t *)nullptr, feat);
+                       mask, count, feat);
     HIP_TRY(hipGetLastError());
     const long long items = (long long)n * (kCells * HIVE_PLANES / 8);
     dim3 grid((unsigned)((items + 255) / 256));
@@ -754,6 +711,36 @@ int hive_encode_launch(const HiveBoard *boards, const HiveHistory *hist, int n, 
 {
     return launch_encode(boards, hist, n, planes, (int)dtype, (int)layout, (unsigned long long *)workspace,
                          (hipStream_t)stream);
+}
+
+int hive_terminal_launch(const HiveBoard *boards, int n, int8_t *over, int8_t *winner, void *stream)
+{
+    if (n <= 0 || boards == nullptr) return fail(HIVE_E_ARG, "terminal: n <= 0 or boards == NULL");
+    hipLaunchKernelGGL(hive_terminal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boards, n,
+                       over, winner);
+    HIP_TRY(hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_step_launch(HiveBoard *boards, HiveHistory *hist, int n, const int32_t *actions, const uint32_t *legal_mask,
+                     void *stream)
+{
+    if (n <= 0 || boards == nullptr || actions == nullptr) return fail(HIVE_E_ARG, "step: bad argument");
+    hipLaunchKernelGGL(hive_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boards, hist,
+                       n, actions, legal_mask, (unsigned long long *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_leaf_launch(const HiveBoard *boards, const HiveHistory *hist, int n, void *planes, HiveDType dtype,
+                     HiveLayout layout, void *workspace, uint32_t *mask, int32_t *count, int8_t *over, int8_t *winner,
+                     void *stream)
+{
+    int rc = launch_encode(boards, hist, n, planes, (int)dtype, (int)layout, (unsigned long long *)workspace,
+                           (hipStream_t)stream, mask, count);
+    if (rc != HIVE_OK) return rc;
+    if (over != nullptr || winner != nullptr) return hive_terminal_launch(boards, n, over, winner, stream);
+    return HIVE_OK;
 }
 
 int hive_batch_create(int n, int device, HiveBatch **out)

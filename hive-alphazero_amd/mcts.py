@@ -1,0 +1,189 @@
+"""TreeSearch / SelfPlay: thousands of PUCT searches in lock step on one MI355X.
+
+Python only sequences kernel launches; the tree (flat SoA node pool), selection, expansion and
+backup are HIP kernels behind include/hive_search.h, leaf positions are expanded and encoded by
+the env kernels (hive_leaf_launch), and the only MFMA work is the batched network forward
+(alpha_net.InferenceNet) on [games x slots] leaves per simulation.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F16, F32, HWC, check, load
+from .config import MAX_GAME_LENGTH
+
+_DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _Params(ctypes.Structure):
+    _fields_ = [("c_puct", ctypes.c_float), ("noise_eps", ctypes.c_float), ("dirichlet_alpha", ctypes.c_float),
+                ("max_game_length", ctypes.c_int32)]
+
+
+class TreeSearch:
+    """`games` independent searches of `sims` simulations each (HivePlayer.action, solo_play.py:110-165).
+
+    evaluator(planes[B,12,12,56]) -> (p fp32 [B,1584] softmax, v fp32 [B])."""
+
+    def __init__(self, games, sims, evaluator, device=None, slots=1, seed=0, plane_dtype=torch.bfloat16,
+                 c_puct=0.7, noise_eps=0.25, dirichlet_alpha=0.3, max_nodes=None):
+        L = load()
+        if L.hive_device_count() <= 0 or not torch.cuda.is_available():
+            raise _lib.HiveError(-2, "no HIP device visible: hive_alphazero_amd has no CPU path")
+        self.L = L
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.games, self.sims, self.slots, self.evaluator = games, sims, slots, evaluator
+        self.max_nodes = max_nodes or (sims + slots + 2)
+        self._h = ctypes.c_void_p()
+        check(L.hive_search_create(games, self.max_nodes, slots, self.device.index, seed, ctypes.byref(self._h)))
+        prm = _Params(c_puct, noise_eps, dirichlet_alpha, MAX_GAME_LENGTH)
+        check(L.hive_search_set_params(self._h, ctypes.byref(prm)))
+        n = games * slots
+        dev = self.device
+        self.plane_dtype = plane_dtype
+        self.leaf_boards = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
+        self.leaf_hist = torch.zeros((n, 384), dtype=torch.uint8, device=dev)
+        self.leaf_mask = torch.zeros((n, 50), dtype=torch.int32, device=dev)
+        self.leaf_count = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.leaf_over = torch.zeros((n,), dtype=torch.int8, device=dev)
+        self.leaf_winner = torch.zeros((n,), dtype=torch.int8, device=dev)
+        self.planes = torch.zeros((n, 12, 12, 56), dtype=plane_dtype, device=dev)
+        self.workspace = torch.zeros((n * 144,), dtype=torch.int64, device=dev)
+        self.policy = torch.zeros((games, 1584), dtype=torch.float32, device=dev)
+        self.action = torch.zeros((games,), dtype=torch.int32, device=dev)
+        self.sum_n = torch.zeros((games,), dtype=torch.int32, device=dev)
+        self.root_planes = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.hive_search_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        s = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.L.hive_search_set_stream(self._h, s))
+        return s
+
+    def search(self, root_boards, root_hist, active=None, selfplay=False, keep_root_planes=False):
+        """-> (action int32[games] (-1 pass, -2 inactive/terminal root), policy fp32[games,1584], sum_n int32[games])"""
+        L, G = self.L, self.games
+        s = self._stream()
+        check(L.hive_search_set_roots(self._h, _p(root_boards), _p(root_hist), _p(active)))
+        done = 0
+        first = True
+        while done < self.sims:
+            k = 1 if first else min(self.slots, self.sims - done)      # the first simulation only opens the root
+            for sl in range(k):
+                check(L.hive_search_select(self._h, sl, _p(self.leaf_boards[sl * G:]), _p(self.leaf_hist[sl * G:])))
+            n = k * G
+            check(L.hive_leaf_launch(_p(self.leaf_boards), _p(self.leaf_hist), n, _p(self.planes), _DT[self.plane_dtype],
+                                     HWC, _p(self.workspace), _p(self.leaf_mask), _p(self.leaf_count),
+                                     _p(self.leaf_over), _p(self.leaf_winner), s))
+            if first and keep_root_planes:
+                self.root_planes = self.workspace[:G * 144].clone()
+            p, v = self.evaluator(self.planes[:n])
+            p = p.float().contiguous()
+            v = v.float().contiguous().view(-1)
+            for sl in range(k):
+                o = sl * G
+                check(L.hive_search_backup(self._h, sl, _p(self.leaf_boards[o:]), _p(self.leaf_hist[o:]),
+                                           _p(self.leaf_mask[o:]), _p(self.leaf_over[o:]), _p(self.leaf_winner[o:]),
+                                           _p(p[o:]), _p(v[o:])))
+            done += k
+            first = False
+        check(L.hive_search_policy(self._h, _p(self.policy), _p(self.action), _p(self.sum_n), 1 if selfplay else 0))
+        return self.action, self.policy, self.sum_n
+
+    def node_counts(self):
+        out = torch.zeros((self.games,), dtype=torch.int32, device=self.device)
+        self._stream()
+        check(self.L.hive_search_node_counts(self._h, _p(out)))
+        return out
+
+
+class SelfPlay:
+    """`games` self-play games advanced ply by ply (woker/self_play.py:116-193 for every game at once):
+    search -> move selection (self-play noise on turns 1..6) -> env step; finished games (queen
+    surrounded or turn >= 55) are scored and replaced by fresh ones.  Records per ply: the packed
+    56-bit-per-cell features of the position, the visit policy and the mover; the value is filled
+    in when the game ends (draw or length cap => -1 for both sides, self_play.py:188-189)."""
+
+    def __init__(self, games, sims, evaluator, device=None, slots=1, seed=0, plane_dtype=torch.bfloat16,
+                 keep_records=True):
+        from .batch import BoardBatch
+        self.games, self.sims = games, sims
+        self.env = BoardBatch(games, device)
+        self.device = self.env.device
+        self.search = TreeSearch(games, sims, evaluator, self.device.index, slots, seed, plane_dtype)
+        self.keep_records = keep_records
+        self.finished = 0
+        self.white_wins = self.black_wins = self.draws = 0
+        self.plies = 0
+        self.finished_lengths = []
+        self.records = []            # (features int64[games,144], policy fp32[games,1584], mover int8[games], game_id)
+        self.game_id = torch.arange(games, device=self.device)
+        self._next_id = games
+
+    def stagger(self, seed=0):
+        """Spread the games over plies 0..53 with uniformly random legal moves so that a timed window
+        sees the steady state."""
+        from .playout import pick_uniform
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(seed)
+        target = torch.randint(0, MAX_GAME_LENGTH - 1, (self.games,), device=self.device, generator=gen)
+        for ply in range(MAX_GAME_LENGTH - 1):
+            over, _ = self.env.terminal()
+            _, count, lst = self.env.legal(want_list=True)
+            a = pick_uniform(count, lst, gen)
+            go = (target > ply) & (over == 0)
+            self.env.step(torch.where(go, a, torch.full_like(a, -2)), sync=False)
+
+    def _retire_finished(self):
+        boards, _ = self.env.export_state()
+        over, winner = self.env.terminal()
+        turn = boards[:, 33].to(torch.int32)
+        done = (over != 0) | (turn >= MAX_GAME_LENGTH)
+        nd = int(done.sum().item())
+        if nd:
+            w = winner[done]
+            self.white_wins += int((w == 1).sum().item())
+            self.black_wins += int((w == 2).sum().item())
+            self.draws += int((w == 0).sum().item())
+            self.finished += nd
+            self.finished_lengths.append(turn[done].float().mean().item())
+            idx = torch.nonzero(done).view(-1).to(torch.int32)
+            self.env.reset(idx)
+            self.game_id[done] = torch.arange(self._next_id, self._next_id + nd, device=self.device)
+            self._next_id += nd
+        return nd
+
+    def play_ply(self):
+        """One move for every game.  Returns the number of games that finished before this move."""
+        nd = self._retire_finished()
+        boards, hist = self.env.export_state()
+        action, policy, sum_n = self.search.search(boards, hist, selfplay=True, keep_root_planes=self.keep_records)
+        if self.keep_records:
+            mover = (1 - (boards[:, 33] & 1)).to(torch.int8)
+            self.records.append((self.search.root_planes.view(self.games, 144), policy.clone(), mover, self.game_id.clone()))
+            if len(self.records) > 64:
+                self.records.pop(0)
+        # the env re-derives the legal masks and refuses anything not in them: the search's edges come
+        # from the same kernels, so illegal_count() must stay 0 (asserted by the tests)
+        self.env.step(action, sync=False)
+        self.plies += 1
+        return nd
+
+    def close(self):
+        self.search.close()
+        self.env.close()

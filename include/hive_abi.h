@@ -131,6 +131,18 @@ int hive_movegen_launch(const HiveBoard *boards, int n, uint32_t *mask, int32_t 
 int hive_encode_launch(const HiveBoard *boards, const HiveHistory *hist, int n, void *planes,
                        HiveDType dtype, HiveLayout layout, void *workspace, void *stream);
 
+/* GamePlay.game_is_over over caller-owned records. */
+int hive_terminal_launch(const HiveBoard *boards, int n, int8_t *over, int8_t *winner, void *stream);
+/* GamePlay.move over caller-owned records: actions as hive_batch_step; legal_mask (uint32[n][50]) may be
+ * NULL when the actions are known to be legal (they come out of the search's own edge lists). */
+int hive_step_launch(HiveBoard *boards, HiveHistory *hist, int n, const int32_t *actions, const uint32_t *legal_mask,
+                     void *stream);
+/* Everything the tree search needs about n leaf positions in one call: planes (as hive_encode_launch),
+ * legal mask / count (may be NULL) and game-over flags (may be NULL). */
+int hive_leaf_launch(const HiveBoard *boards, const HiveHistory *hist, int n, void *planes, HiveDType dtype,
+                     HiveLayout layout, void *workspace, uint32_t *mask, int32_t *count, int8_t *over, int8_t *winner,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

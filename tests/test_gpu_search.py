@@ -1,0 +1,102 @@
+"""GPU tree search (include/hive_search.h) -- invariants, and agreement with the reference-exact
+sequential HivePlayer when the root noise is switched off (both searches are then deterministic)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from mcts_stub import StubPipe, stub_predict   # noqa: E402
+
+
+def _host_stub_evaluator(planes):
+    x = planes.float().cpu().numpy()
+    ps, vs = zip(*(stub_predict(x[i]) for i in range(x.shape[0])))
+    return torch.from_numpy(np.stack(ps)).cuda(), torch.tensor(vs, dtype=torch.float32).cuda()
+
+
+def test_search_invariants():
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd import batch, mcts, packing, playout
+    G, sims = 96, 24
+    boards = playout.random_positions(G, seed=5)
+    B = batch.BoardBatch(G)
+    B.import_state(boards)
+    rb, rh = B.export_state()
+    ts = mcts.TreeSearch(G, sims, _host_stub_evaluator, plane_dtype=torch.float32, seed=3)
+    action, policy, sum_n = ts.search(rb, rh)
+    torch.cuda.synchronize()
+    over, _ = B.terminal()
+    mask, count, _ = B.legal()
+    m = mask.cpu().numpy().view(np.uint32)
+    nodes = ts.node_counts().cpu().numpy()
+    st = packing.unpack_boards(rb.cpu().numpy())
+    for g in range(G):
+        if over[g].item() or st["turn"][g] >= 55:
+            assert action[g].item() == -2
+            continue
+        legal = packing.mask_to_actions(m[g])
+        a = action[g].item()
+        assert (a in legal) if legal else a == -1
+        assert sum_n[g].item() == sims - 1          # the first simulation only evaluates the root
+        assert 1 <= nodes[g] <= sims
+        pol = policy[g].cpu().numpy()
+        assert abs(pol.sum() - 1.0) < 1e-4 or not legal
+        assert set(np.nonzero(pol)[0]).issubset(set(legal))
+    ts.close(); B.close()
+
+
+@pytest.mark.parametrize("prefix_seed,plies", [(21, 0), (22, 3), (23, 8), (24, 14)])
+def test_search_matches_sequential_reference_without_noise(prefix_seed, plies):
+    """noise_eps = 0: the GPU search and solo_play.HivePlayer (pinned to the reference by
+    tests/test_mcts_golden.py) must visit the same root edges the same number of times."""
+    assert torch.cuda.is_available()
+    import hive_alphazero_amd.solo_play as sp
+    from hive_alphazero_amd import batch, mcts
+    from hive_alphazero_amd.env_hive import GamePlay
+    rng = np.random.default_rng(prefix_seed)
+    g = GamePlay(1050, 900)
+    for _ in range(plies):
+        acts = g.actions()
+        g.move(int(acts[rng.integers(len(acts))]))
+    sims = 40
+    sp.SEARCH_THREADS = 1
+    old_eps = sp.noise_eps
+    sp.noise_eps = 0.0
+    try:
+        player = sp.HivePlayer(pipes=[StubPipe()])
+        player.simulation_num_per_move = sims
+        np.random.seed(0)
+        player.action(g)
+        ref = {int(a): int(s.n) for a, s in player.tree[g.state_key].a.items()}
+    finally:
+        sp.noise_eps = old_eps
+    B = batch.BoardBatch(1)
+    B.import_state(g._rec.reshape(1, 64), g._hist.reshape(1, 384))
+    rb, rh = B.export_state()
+    ts = mcts.TreeSearch(1, sims, _host_stub_evaluator, plane_dtype=torch.float32, noise_eps=0.0)
+    action, policy, sum_n = ts.search(rb, rh)
+    pol = policy[0].cpu().numpy()
+    n = int(sum_n[0].item())
+    got = {int(a): int(round(pol[a] * n)) for a in np.nonzero(pol)[0]}
+    assert n == sims - 1
+    assert got == {a: c for a, c in ref.items() if c > 0}
+    ts.close(); B.close()
+
+
+def test_selfplay_engine_runs_and_stays_legal():
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd import mcts
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    torch.manual_seed(0)
+    net = InferenceNet(ChessNet().cuda().eval(), dtype=torch.bfloat16)
+    sp = mcts.SelfPlay(32, 8, net, seed=1)
+    sp.stagger(seed=2)
+    for _ in range(6):
+        sp.play_ply()
+    torch.cuda.synchronize()
+    assert sp.env.illegal_count() == 0
+    assert sp.plies == 6 and len(sp.records) == 6
+    feats, policy, mover, gid = sp.records[-1]
+    assert feats.shape == (32, 144) and policy.shape == (32, 1584)
+    sp.close()
