@@ -42,6 +42,50 @@ def cpu_baseline(boards_np, budget_s=12.0):
             "sample": f"{done} positions ({done // n} passes over the {n}-board corpus), oracle/hive_oracle.c, 1 thread"}
 
 
+GFLOP_PER_LEAF = 6.560114816         # 3,280,057,408 MAC x 2 per board, SURVEY.md 8a a22
+MFMA_PEAK_TFLOPS = 2500.0            # MI355X dense bf16/fp16 matrix peak, MI355X_MICROARCH.md
+
+
+def selfplay_measure(args, local_rank, world):
+    """BASELINE configs[2]: `games` concurrent self-play games, `sims` simulations per move, random-init
+    ChessNet in bf16.  Games are staggered over plies 0..53 so the timed plies see the steady state."""
+    import torch
+    from hive_alphazero_amd import mcts
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    torch.manual_seed(0)
+    net = InferenceNet(ChessNet().cuda().eval(), dtype=torch.bfloat16)
+    sp = mcts.SelfPlay(args.games, args.sims, net, device=local_rank, seed=1234 + local_rank)
+    sp.stagger(seed=77 + local_rank)
+    for _ in range(args.selfplay_warmup):
+        sp.play_ply()
+    torch.cuda.synchronize()
+    f0 = sp.finished
+    t0 = time.perf_counter()
+    for _ in range(args.selfplay_plies):
+        sp.play_ply()
+    sp._retire_finished()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    illegal = sp.env.illegal_count()
+    finished = sp.finished - f0
+    mean_len = (sum(sp.finished_lengths) / len(sp.finished_lengths) - 1.0) if sp.finished_lengths else 54.0
+    leafs = args.games * args.sims * args.selfplay_plies
+    out = {
+        "workload": f"selfplay_{args.games}x{args.sims}sims",
+        "games_per_min": round(args.games * args.selfplay_plies / mean_len / el * 60.0, 2),
+        "finished_games_in_window": finished, "window_plies": args.selfplay_plies, "window_s": round(el, 3),
+        "mean_plies_per_finished_game": round(mean_len, 2), "ms_per_ply": round(el / args.selfplay_plies * 1e3, 2),
+        "leaf_evals_per_s": round(leafs / el, 1),
+        "roofline": {"bound": "mfma", "achieved": round(leafs * GFLOP_PER_LEAF / el / 1e3, 2), "peak": MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(leafs * GFLOP_PER_LEAF / el / 1e3 / MFMA_PEAK_TFLOPS, 5), "traffic": None},
+        "net": "ChessNet 20-block ResNet, random init (torch.manual_seed(0)), bf16 channels-last, HIP-graph replay",
+        "illegal_moves": illegal,
+        "results": {"white": sp.white_wins, "black": sp.black_wins, "draw_or_cap": sp.draws},
+    }
+    sp.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,6 +94,10 @@ def main():
     ap.add_argument("--boards", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sat-boards", type=int, default=1 << 20, help="batch size of the saturated side measurement")
+    ap.add_argument("--games", type=int, default=1024, help="concurrent self-play games per GPU (BASELINE configs[2])")
+    ap.add_argument("--sims", type=int, default=50)
+    ap.add_argument("--selfplay-plies", type=int, default=6, help="timed plies of the self-play side measurement (0 = skip)")
+    ap.add_argument("--selfplay-warmup", type=int, default=1)
     args = ap.parse_args()
 
     import numpy as np
@@ -130,6 +178,15 @@ def main():
                "frac_of_hbm_peak": round(nb * ALGO_BYTES_PER_BOARD / ms / 1e6 / HBM_PEAK_GBS, 5)}
         del big, bm, bc
 
+    selfplay = None
+    if args.selfplay_plies > 0:
+        selfplay = selfplay_measure(args, local_rank, world)
+        if world > 1:
+            t = torch.tensor([selfplay["games_per_min"], selfplay["leaf_evals_per_s"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            selfplay["games_per_min_all_gpus"] = round(float(t[0].item()), 2)
+            selfplay["leaf_evals_per_s_all_gpus"] = round(float(t[1].item()), 1)
+
     if rank == 0:
         launch_us = dev_ms * 1e3 / args.steps
         achieved = n * ALGO_BYTES_PER_BOARD / (launch_us * 1e-6) / 1e9
@@ -150,10 +207,11 @@ def main():
                        "corpus": "GPU random playouts, every ply sampled, seed 1000+rank", "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "kernel": "hive_env_kernel<false,0,0>", "launch_us": round(launch_us, 3),
+                         "kernel": "hive_piece_kernel<false>", "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_BOARD,
-                         "note": "VALU/LDS-latency bound at 4096 boards (64 workgroups on 256 CUs); see saturated"},
+                         "note": "VALU-issue bound: 4096 boards = 256 workgroups x 11 waves, ~2.75 waves per SIMD; see saturated"},
             "saturated": sat,
+            "selfplay": selfplay,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(boards.cpu().numpy())
