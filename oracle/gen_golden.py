@@ -271,6 +271,60 @@ def cmd_mcts(a):
     print("mcts.json.gz written")
 
 
+def cmd_uct(a):
+    """alpha_zero/MCTS_chess.py::UCTNode driven by UCT_search's loop (:130-151) with the stub evaluator
+    (UCT_search itself hard-codes .cuda() at :138, so its five-line loop is restated here)."""
+    from alpha_zero.MCTS_chess import UCTNode, DummyNode
+    cases = []
+    for ci, pre_plies in enumerate([0, 3, 11, 22]):
+        rng = np.random.default_rng(300 + ci)
+        g = _new_game()
+        prefix = []
+        for _ in range(pre_plies):
+            act = choose(g, rng, "uniform")
+            prefix.append(act)
+            g.move(act)
+        root = UCTNode(g, move=None, parent=DummyNode())
+        for _ in range(a.reads):
+            leaf = root.select_leaf()
+            p, v = stub_predict(leaf.game.encode_board())
+            if leaf.game.game_is_over():
+                leaf.backup(v)
+                continue
+            leaf.expand(p)
+            leaf.backup(v)
+        nz = np.nonzero(root.child_number_visits)[0]
+        cases.append({"prefix": prefix, "reads": a.reads, "best": int(np.argmax(root.child_number_visits)),
+                      "visits": [[int(i), float(root.child_number_visits[i]), float(root.child_total_value[i])] for i in nz]})
+        print("uct case", ci, cases[-1]["best"], len(nz), flush=True)
+    with open(os.path.join(GOLD, "uct.json"), "w") as f:
+        json.dump({"cases": cases}, f, separators=(",", ":"))
+
+
+def cmd_selfplay(a):
+    """woker/self_play_with_train.py::self_play_buffer (the working twin of woker/self_play.py, SURVEY 0.4)
+    at SEARCH_THREADS=1, `sims` simulations, stub evaluator, seeded numpy: one full game."""
+    import contextlib
+    import io
+    import zlib
+    import woker.solo_play as sp
+    sp.SEARCH_THREADS = 1
+    sp.simulation_num_per_move = a.sims
+    import woker.self_play_with_train as st
+    np.random.seed(a.seed)
+    cur = [[StubPipe()]]
+    with contextlib.redirect_stdout(io.StringIO()):
+        data, value_white = st.self_play_buffer(cur)
+    rows = []
+    for state, policy, value, lens in data:
+        arr = np.asarray(state, dtype=np.float32)
+        rows.append({"crc": int(zlib.crc32(arr.tobytes())), "turn": int(arr[0, 0, 31]),
+                     "pol": [[i, float(x)] for i, x in enumerate(policy) if x != 0], "v": value, "lens": lens})
+    with gzip.open(os.path.join(GOLD, "selfplay.json.gz"), "wt", compresslevel=9) as f:
+        json.dump({"seed": a.seed, "sims": a.sims, "value_white": value_white, "rows": rows}, f, separators=(",", ":"))
+    print("selfplay.json.gz rows", len(rows), "value_white", value_white)
+
+
 def cmd_net(a):
     """alpha_zero/alpha_net.py::ChessNet: (1) same-seed init of the build's ChessNet gives identical
     tensors, (2) outputs of the reference net on planes of golden positions (CPU fp32)."""
@@ -327,5 +381,11 @@ if __name__ == "__main__":
     pm.add_argument("--sims", type=int, default=50)
     pn = sub.add_parser("net")
     pn.add_argument("--seed", type=int, default=0)
+    pu = sub.add_parser("uct")
+    pu.add_argument("--reads", type=int, default=40)
+    ps = sub.add_parser("selfplay")
+    ps.add_argument("--sims", type=int, default=5)
+    ps.add_argument("--seed", type=int, default=4)
     a = ap.parse_args()
-    {"tables": cmd_tables, "games": cmd_games, "mcts": cmd_mcts, "net": cmd_net}[a.cmd](a)
+    {"tables": cmd_tables, "games": cmd_games, "mcts": cmd_mcts, "net": cmd_net, "uct": cmd_uct,
+     "selfplay": cmd_selfplay}[a.cmd](a)

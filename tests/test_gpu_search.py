@@ -100,3 +100,46 @@ def test_selfplay_engine_runs_and_stays_legal():
     feats, policy, mover, gid = sp.records[-1]
     assert feats.shape == (32, 144) and policy.shape == (32, 1584)
     sp.close()
+
+
+def test_uct_search_and_model_api_gpu(golden_games):
+    """The array-tree search (MCTS_chess.UCT_search) and the pipe-served evaluator (api_hive.HiveModelAPI)
+    on the GPU env / GPU net."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.MCTS_chess import UCT_search, get_policy
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    from hive_alphazero_amd.api_hive import HiveModelAPI
+    from hive_alphazero_amd.env_hive import GamePlay
+    torch.manual_seed(0)
+    net = ChessNet().cuda().eval()
+    inf = InferenceNet(net, dtype=torch.float32)
+    g = GamePlay(1050, 900)
+    for rec in golden_games[0]["plies"][:6]:
+        g.move(rec["a"])
+    legal = g.actions()
+    best, root, _ = UCT_search(g, 16, inf)
+    assert int(best) in legal
+    pol = get_policy(root)
+    assert abs(pol.sum() - 1.0) < 1e-5 and set(np.nonzero(pol)[0]).issubset(set(legal))
+    assert root.child_number_visits.sum() == 15          # the first read expands the root
+    best2, root2, _ = UCT_search(g, 16, net)             # plain ChessNet, NCHW fp32 like the reference
+    assert np.array_equal(root.child_number_visits, root2.child_number_visits)
+
+    api = HiveModelAPI(inf)
+    pipes = [api.create_pipe() for _ in range(6)]
+    api.start()
+    planes = []
+    for i, rec in enumerate(golden_games[1]["plies"][3:9]):
+        pl = np.zeros((12, 12, 56), dtype=np.float64)
+        pl.reshape(-1)[rec["planes"]] = 1.0
+        pl[:, :, 31] = rec["t"]
+        planes.append(pl)
+        pipes[i].send(pl)
+    x = torch.from_numpy(np.stack(planes).astype(np.float32)).cuda()
+    p_ref, v_ref = inf(x)
+    for i, pipe in enumerate(pipes):
+        assert pipe.poll(30)
+        p, v = pipe.recv()
+        assert isinstance(v, float) and p.shape == (1584,)
+        assert np.allclose(p, p_ref[i].cpu().numpy(), atol=1e-5) and abs(v - float(v_ref[i])) < 1e-4
+    api.stop()
