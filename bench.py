@@ -21,6 +21,9 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_BOARD = 262          # 64 B HiveBoard read + 198 B (1584-bit) legal mask written, SURVEY.md 8d
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+# HBM bytes per board from the PMC passes in profiles/r01_movegen_pmc_traffic.md: (2 x FETCH_SIZE + WRITE_SIZE) KiB
+# per 4096-board launch = 1,339,392 B (gfx950 FETCH_SIZE correction applied); not measurable from inside bench.py
+MOVEGEN_TRAFFIC_BYTES_PER_BOARD = 327
 
 
 def cpu_baseline(boards_np, budget_s=12.0):
@@ -206,7 +209,7 @@ def main():
             "config": {"workload": f"movegen_{n}", "boards_per_step_per_gpu": n, "mean_legal_moves": round(mean_legal, 2),
                        "corpus": "GPU random playouts, every ply sampled, seed 1000+rank", "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": MOVEGEN_TRAFFIC_BYTES_PER_BOARD * n,
                          "kernel": "hive_piece_kernel<false>", "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_BOARD,
                          "note": "VALU-issue bound: 4096 boards = 256 workgroups x 11 waves, ~2.75 waves per SIMD; see saturated"},
