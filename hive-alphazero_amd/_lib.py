@@ -35,6 +35,8 @@ ABI_SYMBOLS = [
     "hive_search_create", "hive_search_destroy", "hive_search_set_stream", "hive_search_set_params",
     "hive_search_set_roots", "hive_search_select", "hive_search_backup", "hive_search_policy",
     "hive_search_node_counts",
+    # include/hive_nn.h
+    "hive_nn_conv3x3",
 ]
 
 
@@ -97,6 +99,7 @@ def load():
     L.hive_search_backup.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.hive_search_policy.argtypes = [vp, vp, vp, vp, i32]
     L.hive_search_node_counts.argtypes = [vp, vp]
+    L.hive_nn_conv3x3.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp]
     for name in ABI_SYMBOLS:
         getattr(L, name)
     _lib = L

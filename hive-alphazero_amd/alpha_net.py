@@ -143,14 +143,48 @@ def _fold(conv, bn):
     return w * scale.view(-1, 1, 1, 1), bn.bias.detach().float() + (b - bn.running_mean.detach().float()) * scale
 
 
-class InferenceNet:
-    """Batched leaf evaluator for a ChessNet (eval mode).  __call__(planes_hwc) -> (p fp32 [B,1584], v fp32 [B])."""
+def _frag_major(w, dev):
+    """[256, cin, 3, 3] fp32 -> bf16 [9][cinp/32][16][64][8]: the MFMA-fragment-major weight layout of
+    hive_nn_conv3x3 (include/hive_nn.h).  tap = dy*3+dx; cin zero-padded to a multiple of 64; inside a
+    (tap, 32-channel k-step, 16-output-channel tile) block, lane = (c%32)//8*16 + k%16 holds 8 consecutive c."""
+    k, cin = w.shape[0], w.shape[1]
+    cinp = (cin + 63) // 64 * 64
+    t = w.permute(2, 3, 0, 1).reshape(9, k, cin)
+    if cinp != cin:
+        t = torch.cat([t, torch.zeros(9, k, cinp - cin, dtype=t.dtype, device=t.device)], dim=2)
+    t = t.reshape(9, 16, 16, cinp // 32, 4, 8)          # tap, m-tile, row, k-step, k-group, 8
+    t = t.permute(0, 3, 1, 4, 2, 5)                     # tap, k-step, m-tile, k-group, row, 8
+    return t.to(dev, torch.bfloat16).contiguous()
 
-    def __init__(self, net, dtype=torch.bfloat16, device=None, use_graph=True):
+
+class InferenceNet:
+    """Batched leaf evaluator for a ChessNet (eval mode).  __call__(planes_hwc) -> (p fp32 [B,1584], v fp32 [B]).
+
+    conv = "hip" (default for bf16 on a GPU): the 39 3x3 convolutions run in the hand-written MFMA
+    kernel hive_nn_conv3x3 with bias / skip / ReLU fused; conv = "torch": MIOpen through F.conv2d."""
+
+    def __init__(self, net, dtype=torch.bfloat16, device=None, use_graph=True, conv=None):
         dev = torch.device(device) if device is not None else next(net.parameters()).device
         self.device, self.dtype, self.use_graph = dev, dtype, use_graph and dev.type == "cuda"
+        if conv is None:
+            conv = "hip" if (dev.type == "cuda" and dtype == torch.bfloat16) else "torch"
+        if conv == "hip" and not (dev.type == "cuda" and dtype == torch.bfloat16):
+            raise ValueError("the HIP convolution path is bf16 on a GPU")
+        self.conv = conv
         net = net.eval()
         cl = torch.channels_last
+        if conv == "hip":
+            from . import _lib
+            self._L = _lib.load()
+            w, b = _fold(net.conv.conv1, net.conv.bn1)
+            self.h_stem = (_frag_major(w, dev), b.to(dev, torch.float32).contiguous())
+            self.h_blocks = []
+            for i in range(19):
+                rb = getattr(net, "res_%i" % i)
+                w1, b1 = _fold(rb.conv1, rb.bn1)
+                w2, b2 = _fold(rb.conv2, rb.bn2)
+                self.h_blocks.append((_frag_major(w1, dev), b1.to(dev, torch.float32).contiguous(),
+                                      _frag_major(w2, dev), b2.to(dev, torch.float32).contiguous()))
 
         def prep(w, b):
             return (w.to(dev, dtype).contiguous(memory_format=cl), b.to(dev, dtype))
@@ -170,14 +204,39 @@ class InferenceNet:
         self.fc2 = (ob.fc2.weight.detach().to(dev, torch.float32), ob.fc2.bias.detach().to(dev, torch.float32))
         self._graphs = {}
 
+    def _conv_hip(self, x, cin, w, b, res, out):
+        import ctypes
+        from ._lib import check
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self._L.hive_nn_conv3x3(ctypes.c_void_p(x.data_ptr()), cin, ctypes.c_void_p(w.data_ptr()),
+                                      ctypes.c_void_p(b.data_ptr()),
+                                      ctypes.c_void_p(res.data_ptr()) if res is not None else None,
+                                      ctypes.c_void_p(out.data_ptr()), x.shape[0], 1, st))
+        return out
+
+    def _tower_hip(self, x_hwc):
+        B = x_hwc.shape[0]
+        x_hwc = x_hwc.contiguous()
+        bufs = [torch.empty((B, 12, 12, 256), dtype=torch.bfloat16, device=self.device) for _ in range(3)]
+        s = self._conv_hip(x_hwc, 56, self.h_stem[0], self.h_stem[1], None, bufs[0])
+        cur = 0
+        for w1, b1, w2, b2 in self.h_blocks:
+            o = self._conv_hip(s, 256, w1, b1, None, bufs[(cur + 1) % 3])
+            s2 = self._conv_hip(o, 256, w2, b2, s, bufs[(cur + 2) % 3])      # relu(conv + bias + skip)
+            s, cur = s2, (cur + 2) % 3
+        return s.permute(0, 3, 1, 2)             # NCHW view with channels-last strides
+
     def _forward(self, x_hwc):
         # x_hwc: [B,12,12,56] in self.dtype; viewed as NCHW with channels-last strides (zero copy)
-        x = x_hwc.permute(0, 3, 1, 2)
-        s = F.relu(F.conv2d(x, self.stem[0], self.stem[1], padding=1))
-        for (w1, b1), (w2, b2) in self.blocks:
-            o = F.relu(F.conv2d(s, w1, b1, padding=1))
-            o = F.conv2d(o, w2, b2, padding=1)
-            s = F.relu(o + s)
+        if self.conv == "hip":
+            s = self._tower_hip(x_hwc)
+        else:
+            x = x_hwc.permute(0, 3, 1, 2)
+            s = F.relu(F.conv2d(x, self.stem[0], self.stem[1], padding=1))
+            for (w1, b1), (w2, b2) in self.blocks:
+                o = F.relu(F.conv2d(s, w1, b1, padding=1))
+                o = F.conv2d(o, w2, b2, padding=1)
+                s = F.relu(o + s)
         B = s.shape[0]
         v = F.relu(F.conv2d(s, self.vconv[0], self.vconv[1])).float().reshape(B, 144)
         v = F.relu(F.linear(v, *self.fc1))

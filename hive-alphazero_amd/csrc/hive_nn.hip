@@ -1,0 +1,162 @@
+// hive_nn.hip -- 3x3 convolution of the 12x12x256 residual tower as an implicit GEMM on the CDNA4
+// matrix cores (v_mfma_f32_16x16x32_bf16), fused with bias, skip connection and ReLU.
+//
+// One workgroup (4 waves) = one board.  GEMM view per board: D[k][pixel] = sum_{tap,c} W[tap][k][c] *
+// X[pixel + tap][c]  (M = 256 output channels, N = 144 pixels, K = 9 * C_in).
+//   * The board (144 pixels x C_in bf16, 74 KB) is staged ONCE in LDS; the nine taps are nine
+//     shifted views of it, out-of-board pixels read as zero (no halo in LDS, so two workgroups fit
+//     a CU and one stages while the other computes).  Pixel stride = 2*C_in + 32 bytes: the
+//     ds_read_b128 of a B fragment (16 pixels x 4 k-groups) is bank-conflict free.
+//   * Each wave owns 64 output channels (4 M tiles) x all 9 pixel tiles = 36 accumulator tiles
+//     (144 VGPRs); per 32-deep k-step it reads 9 B fragments from LDS (shared by the 4 waves) and
+//     4 A fragments (weights) straight from L2 into registers, double buffered one step ahead.
+//   * D's layout puts 4 consecutive output channels of one pixel in each lane: the epilogue adds
+//     bias (+ skip), applies ReLU, rounds once to bf16 and stores 8 bytes per lane, channels-last.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/hive_abi.h"
+#include "../../include/hive_nn.h"
+
+namespace hive {
+int set_error(int code, const std::string &msg);
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CINP, bool RES>
+__global__ void __launch_bounds__(256, 2)
+conv3x3_kernel(const __bf16 *__restrict__ X, int cin, const __bf16 *__restrict__ W, const float *__restrict__ bias,
+               const __bf16 *__restrict__ R, __bf16 *__restrict__ Y, int relu)
+{
+    constexpr int PS = CINP * 2 + 32;          // pixel stride in LDS, bytes
+    constexpr int KC = CINP / 32;              // 32-deep k-steps per tap
+    __shared__ __attribute__((aligned(16))) unsigned char lds[144 * PS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const long long b = blockIdx.x;
+
+    // ---- stage the board: 16-byte chunks, zero the channel padding
+    {
+        const int cpp = cin * 2 / 16;                       // chunks per pixel in global memory
+        const uint4 *src = reinterpret_cast<const uint4 *>(X + b * 144 * cin);
+        for (int i = tid; i < 144 * cpp; i += 256) {
+            int pix = i / cpp, c = i - pix * cpp;
+            *reinterpret_cast<uint4 *>(lds + pix * PS + c * 16) = src[i];
+        }
+        const int padc = CINP * 2 / 16 - cpp;               // 0 or 1 chunk of zero channels
+        for (int i = tid; i < 144 * padc; i += 256) {
+            int pix = i / padc, c = cpp + (i - pix * padc);
+            *reinterpret_cast<uint4 *>(lds + pix * PS + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    // packed (row << 4 | col) of this lane's pixel in each of the 9 pixel tiles
+    unsigned pyx[9];
+#pragma unroll
+    for (int nt = 0; nt < 9; ++nt) {
+        unsigned pixel = (unsigned)(nt * 16 + lr);
+        unsigned y = pixel / 12u;
+        pyx[nt] = (y << 4) | (pixel - 12u * y);
+    }
+    f32x4 acc[4][9];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 9; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // weights are stored fragment-major: W[tap][kc][m-tile][lane][8], so one A fragment of a wave is
+    // one contiguous 1 KiB block (full 128-byte lines from L2, no 16-row gather)
+    const __bf16 *wbase = W + ((size_t)(wave * 4) * 64 + lane) * 8;
+    bf16x8 A[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) A[0][mt] = *reinterpret_cast<const bf16x8 *>(wbase + (size_t)mt * 512);
+    __syncthreads();
+
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        // LDS byte offset of the shifted pixel, or 0xFFFFFFFF when it falls off the board (reads as zero)
+        unsigned boff[9];
+#pragma unroll
+        for (int nt = 0; nt < 9; ++nt) {
+            int sy = (int)(pyx[nt] >> 4) + dy, sx = (int)(pyx[nt] & 15u) + dx;
+            bool inb = (unsigned)sy < 12u && (unsigned)sx < 12u;
+            boff[nt] = inb ? (unsigned)((sy * 12 + sx) * PS + lg * 16) : 0xFFFFFFFFu;
+        }
+#pragma unroll 1
+        for (int kc2 = 0; kc2 < KC; kc2 += 2) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int kc = kc2 + half;
+                // prefetch the next step's weight fragments into the other buffer
+                {
+                    int nkc = kc + 1, ntap = tap;
+                    if (nkc == KC) { nkc = 0; ntap = tap + 1; }
+                    if (ntap < 9) {
+                        const __bf16 *wp = wbase + (size_t)(ntap * KC + nkc) * (16 * 512);
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            A[half ^ 1][mt] = *reinterpret_cast<const bf16x8 *>(wp + (size_t)mt * 512);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < 9; ++nt) {
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (boff[nt] != 0xFFFFFFFFu) v = *reinterpret_cast<const uint4 *>(lds + boff[nt] + kc * 64);
+                    const bf16x8 Bf = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[half][mt], Bf, acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds D[ch0 .. ch0+3][pixel], ch0 = wave*64 + mt*16 + lg*4, pixel = nt*16 + lr
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int ch0 = wave * 64 + mt * 16 + lg * 4;
+        const float4 bv = *reinterpret_cast<const float4 *>(bias + ch0);
+#pragma unroll
+        for (int nt = 0; nt < 9; ++nt) {
+            const int pixel = nt * 16 + lr;
+            const size_t o = ((size_t)b * 144 + pixel) * 256 + ch0;
+            float v0 = acc[mt][nt][0] + bv.x, v1 = acc[mt][nt][1] + bv.y, v2 = acc[mt][nt][2] + bv.z,
+                  v3 = acc[mt][nt][3] + bv.w;
+            if (RES) {
+                bf16x4 r = *reinterpret_cast<const bf16x4 *>(R + o);
+                v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+            }
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            bf16x4 out = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+            *reinterpret_cast<bf16x4 *>(Y + o) = out;
+        }
+    }
+}
+
+}  // namespace hive
+
+using namespace hive;
+
+extern "C" int hive_nn_conv3x3(const void *x, int cin, const void *w, const float *bias, const void *residual, void *y,
+                               int batch, int relu, void *stream)
+{
+    if (!x || !w || !bias || !y || batch <= 0) return set_error(HIVE_E_ARG, "hive_nn_conv3x3: bad argument");
+    const __bf16 *X = (const __bf16 *)x, *Wt = (const __bf16 *)w, *R = (const __bf16 *)residual;
+    __bf16 *Y = (__bf16 *)y;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)batch), block(256);
+    if (cin == 256) {
+        if (R) hipLaunchKernelGGL((conv3x3_kernel<256, true>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
+        else hipLaunchKernelGGL((conv3x3_kernel<256, false>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
+    } else if (cin == 56) {
+        if (R) hipLaunchKernelGGL((conv3x3_kernel<64, true>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
+        else hipLaunchKernelGGL((conv3x3_kernel<64, false>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
+    } else {
+        return set_error(HIVE_E_ARG, "hive_nn_conv3x3: cin must be 56 or 256");
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(HIVE_E_DEVICE, std::string("hive_nn_conv3x3: ") + hipGetErrorString(e));
+    return HIVE_OK;
+}

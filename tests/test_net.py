@@ -81,3 +81,58 @@ def test_inference_net_gpu_tolerances():
         _check(p2, v2, gold, atol_p, atol_v)                    # stated tolerance of the reduced-precision engine
         p3, v3 = inf(x)                                         # graph replay is deterministic
         assert torch.equal(p2, p3) and torch.equal(v2, v3)
+
+
+@pytest.mark.gpu
+def test_hip_conv3x3_matches_torch():
+    """hive_nn_conv3x3 (MFMA implicit GEMM, fused bias/skip/ReLU) against F.conv2d in fp32 on the same
+    bf16-rounded operands.  Tolerance: one bf16 rounding of the output (2^-8 relative) + fp32
+    accumulation-order noise."""
+    assert torch.cuda.is_available()
+    import ctypes
+    import torch.nn.functional as F
+    import hive_alphazero_amd as h
+    from hive_alphazero_amd.alpha_net import _frag_major
+    L = h.load()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for cin, B in ((256, 5), (56, 3)):
+        x = torch.randn((B, 12, 12, cin), device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn((256, cin, 3, 3), device="cuda", generator=g) * (2.0 / (9 * cin)) ** 0.5)
+        bias = torch.randn((256,), device="cuda", generator=g)
+        res = torch.randn((B, 12, 12, 256), device="cuda", generator=g).to(torch.bfloat16)
+        wt = _frag_major(w, x.device)
+        wq = w.to(torch.bfloat16).float()
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), wq, bias, padding=1)
+        for use_res in (False, True):
+            for relu in (0, 1):
+                want = ref + (res.float().permute(0, 3, 1, 2) if use_res else 0)
+                if relu:
+                    want = torch.relu(want)
+                want = want.permute(0, 2, 3, 1)
+                y = torch.full((B, 12, 12, 256), float("nan"), dtype=torch.bfloat16, device="cuda")
+                rc = L.hive_nn_conv3x3(ctypes.c_void_p(x.data_ptr()), cin, ctypes.c_void_p(wt.data_ptr()),
+                                       ctypes.c_void_p(bias.data_ptr()),
+                                       ctypes.c_void_p(res.data_ptr()) if use_res else None,
+                                       ctypes.c_void_p(y.data_ptr()), B, relu, None)
+                assert rc == 0
+                torch.cuda.synchronize()
+                err = (y.float() - want).abs()
+                tol = 1e-2 * want.abs() + 2e-2
+                assert bool((err <= tol).all()), (cin, use_res, relu, float(err.max()))
+                assert float(err.mean()) < 5e-3
+
+
+@pytest.mark.gpu
+def test_inference_net_hip_vs_torch_backend():
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    gold = _gold()
+    torch.manual_seed(gold["seed"])
+    net = ChessNet().eval().cuda()
+    x = _inputs(gold).cuda()
+    a = InferenceNet(net, dtype=torch.bfloat16, conv="hip")
+    b = InferenceNet(net, dtype=torch.bfloat16, conv="torch")
+    pa, va = a(x)
+    pb, vb = b(x)
+    _check(pa, va, gold, 2e-4, 3e-2)
+    assert float((pa - pb).abs().max()) < 2e-4 and float((va - vb).abs().max()) < 3e-2
