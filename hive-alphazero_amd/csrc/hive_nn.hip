@@ -33,7 +33,8 @@ conv3x3_kernel(const __bf16 *__restrict__ X, int cin, const __bf16 *__restrict__
 {
     constexpr int PS = CINP * 2 + 32;          // pixel stride in LDS, bytes
     constexpr int KC = CINP / 32;              // 32-deep k-steps per tap
-    __shared__ __attribute__((aligned(16))) unsigned char lds[144 * PS];
+    constexpr unsigned ZOFF = 144 * PS;        // a zeroed pixel: what every off-board tap reads
+    __shared__ __attribute__((aligned(16))) unsigned char lds[145 * PS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const long long b = blockIdx.x;
@@ -46,6 +47,8 @@ conv3x3_kernel(const __bf16 *__restrict__ X, int cin, const __bf16 *__restrict__
             int pix = i / cpp, c = i - pix * cpp;
             *reinterpret_cast<uint4 *>(lds + pix * PS + c * 16) = src[i];
         }
+        for (int i = tid; i < PS / 16; i += 256)
+            *reinterpret_cast<uint4 *>(lds + ZOFF + i * 16) = make_uint4(0u, 0u, 0u, 0u);
         const int padc = CINP * 2 / 16 - cpp;               // 0 or 1 chunk of zero channels
         for (int i = tid; i < 144 * padc; i += 256) {
             int pix = i / padc, c = cpp + (i - pix * padc);
@@ -76,13 +79,14 @@ conv3x3_kernel(const __bf16 *__restrict__ X, int cin, const __bf16 *__restrict__
 
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        // LDS byte offset of the shifted pixel, or 0xFFFFFFFF when it falls off the board (reads as zero)
+        // LDS byte offset of the shifted pixel; off-board taps read the zero pixel (no exec-masked loads,
+        // so the ds_reads can be issued ahead of the MFMAs that consume them)
         unsigned boff[9];
 #pragma unroll
         for (int nt = 0; nt < 9; ++nt) {
             int sy = (int)(pyx[nt] >> 4) + dy, sx = (int)(pyx[nt] & 15u) + dx;
             bool inb = (unsigned)sy < 12u && (unsigned)sx < 12u;
-            boff[nt] = inb ? (unsigned)((sy * 12 + sx) * PS + lg * 16) : 0xFFFFFFFFu;
+            boff[nt] = (inb ? (unsigned)((sy * 12 + sx) * PS) : ZOFF) + (unsigned)(lg * 16);
         }
 #pragma unroll 1
         for (int kc2 = 0; kc2 < KC; kc2 += 2) {
@@ -102,9 +106,7 @@ conv3x3_kernel(const __bf16 *__restrict__ X, int cin, const __bf16 *__restrict__
                 }
 #pragma unroll
                 for (int nt = 0; nt < 9; ++nt) {
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (boff[nt] != 0xFFFFFFFFu) v = *reinterpret_cast<const uint4 *>(lds + boff[nt] + kc * 64);
-                    const bf16x8 Bf = __builtin_bit_cast(bf16x8, v);
+                    const bf16x8 Bf = *reinterpret_cast<const bf16x8 *>(lds + boff[nt] + kc * 64);
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[half][mt], Bf, acc[mt][nt], 0, 0, 0);
