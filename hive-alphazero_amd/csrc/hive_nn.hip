@@ -19,6 +19,10 @@
 #include "../../include/hive_abi.h"
 #include "../../include/hive_nn.h"
 
+#ifndef HIVE_CONV_WAVES
+#define HIVE_CONV_WAVES 4      // waves per board workgroup (4: 4 M tiles per wave, 2 workgroups per CU; measured faster than 8)
+#endif
+
 namespace hive {
 int set_error(int code, const std::string &msg);
 
@@ -26,13 +30,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int CINP, bool RES>
-__global__ void __launch_bounds__(256, 2)
+template <int CINP, bool RES, int NWAVE>
+__global__ void __launch_bounds__(NWAVE * 64, NWAVE / 2)
 conv3x3_kernel(const __bf16 *__restrict__ X, int cin, const __bf16 *__restrict__ W, const float *__restrict__ bias,
                const __bf16 *__restrict__ R, __bf16 *__restrict__ Y, int relu)
 {
     constexpr int PS = CINP * 2 + 32;          // pixel stride in LDS, bytes
     constexpr int KC = CINP / 32;              // 32-deep k-steps per tap
+    constexpr int MT = 16 / NWAVE;             // 16-channel M tiles per wave
+    constexpr int NT = NWAVE * 64;             // threads
     constexpr unsigned ZOFF = 144 * PS;        // a zeroed pixel: what every off-board tap reads
     __shared__ __attribute__((aligned(16))) unsigned char lds[145 * PS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -43,38 +49,34 @@ conv3x3_kernel(const __bf16 *__restrict__ X, int cin, const __bf16 *__restrict__
     {
         const int cpp = cin * 2 / 16;                       // chunks per pixel in global memory
         const uint4 *src = reinterpret_cast<const uint4 *>(X + b * 144 * cin);
-        for (int i = tid; i < 144 * cpp; i += 256) {
+#ifdef HIVE_CONV_ABL_STAGE
+        for (int i = tid; i < 1 * cpp; i += NT) {
+#else
+        for (int i = tid; i < 144 * cpp; i += NT) {
+#endif
             int pix = i / cpp, c = i - pix * cpp;
             *reinterpret_cast<uint4 *>(lds + pix * PS + c * 16) = src[i];
         }
-        for (int i = tid; i < PS / 16; i += 256)
+        for (int i = tid; i < PS / 16; i += NT)
             *reinterpret_cast<uint4 *>(lds + ZOFF + i * 16) = make_uint4(0u, 0u, 0u, 0u);
         const int padc = CINP * 2 / 16 - cpp;               // 0 or 1 chunk of zero channels
-        for (int i = tid; i < 144 * padc; i += 256) {
+        for (int i = tid; i < 144 * padc; i += NT) {
             int pix = i / padc, c = cpp + (i - pix * padc);
             *reinterpret_cast<uint4 *>(lds + pix * PS + c * 16) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
-    // packed (row << 4 | col) of this lane's pixel in each of the 9 pixel tiles
-    unsigned pyx[9];
+    f32x4 acc[MT][9];
 #pragma unroll
-    for (int nt = 0; nt < 9; ++nt) {
-        unsigned pixel = (unsigned)(nt * 16 + lr);
-        unsigned y = pixel / 12u;
-        pyx[nt] = (y << 4) | (pixel - 12u * y);
-    }
-    f32x4 acc[4][9];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 9; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // weights are stored fragment-major: W[tap][kc][m-tile][lane][8], so one A fragment of a wave is
     // one contiguous 1 KiB block (full 128-byte lines from L2, no 16-row gather)
-    const __bf16 *wbase = W + ((size_t)(wave * 4) * 64 + lane) * 8;
-    bf16x8 A[2][4];
+    const __bf16 *wbase = W + ((size_t)(wave * MT) * 64 + lane) * 8;
+    bf16x8 A[2][MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) A[0][mt] = *reinterpret_cast<const bf16x8 *>(wbase + (size_t)mt * 512);
+    for (int mt = 0; mt < MT; ++mt) A[0][mt] = *reinterpret_cast<const bf16x8 *>(wbase + (size_t)mt * 512);
     __syncthreads();
 
     for (int tap = 0; tap < 9; ++tap) {
@@ -84,7 +86,8 @@ conv3x3_kernel(const __bf16 *__restrict__ X, int cin, const __bf16 *__restrict__
         unsigned boff[9];
 #pragma unroll
         for (int nt = 0; nt < 9; ++nt) {
-            int sy = (int)(pyx[nt] >> 4) + dy, sx = (int)(pyx[nt] & 15u) + dx;
+            const int pixel = nt * 16 + lr, y0 = pixel / 12;      // recomputed per tap: cheaper than 9 live VGPRs
+            int sy = y0 + dy, sx = pixel - 12 * y0 + dx;
             bool inb = (unsigned)sy < 12u && (unsigned)sx < 12u;
             boff[nt] = (inb ? (unsigned)((sy * 12 + sx) * PS) : ZOFF) + (unsigned)(lg * 16);
         }
@@ -97,10 +100,14 @@ conv3x3_kernel(const __bf16 *__restrict__ X, int cin, const __bf16 *__restrict__
                 {
                     int nkc = kc + 1, ntap = tap;
                     if (nkc == KC) { nkc = 0; ntap = tap + 1; }
+#ifdef HIVE_CONV_ABL_A
+                    if (false) {
+#else
                     if (ntap < 9) {
+#endif
                         const __bf16 *wp = wbase + (size_t)(ntap * KC + nkc) * (16 * 512);
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
+                        for (int mt = 0; mt < MT; ++mt)
                             A[half ^ 1][mt] = *reinterpret_cast<const bf16x8 *>(wp + (size_t)mt * 512);
                     }
                 }
@@ -108,20 +115,25 @@ conv3x3_kernel(const __bf16 *__restrict__ X, int cin, const __bf16 *__restrict__
                 for (int nt = 0; nt < 9; ++nt) {
                     const bf16x8 Bf = *reinterpret_cast<const bf16x8 *>(lds + boff[nt] + kc * 64);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
+                    for (int mt = 0; mt < MT; ++mt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[half][mt], Bf, acc[mt][nt], 0, 0, 0);
                 }
             }
         }
     }
 
-    // ---- epilogue: lane holds D[ch0 .. ch0+3][pixel], ch0 = wave*64 + mt*16 + lg*4, pixel = nt*16 + lr
+    // ---- epilogue: lane holds D[ch0 .. ch0+3][pixel], ch0 = (wave*MT + mt)*16 + lg*4, pixel = nt*16 + lr
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int ch0 = wave * 64 + mt * 16 + lg * 4;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int ch0 = (wave * MT + mt) * 16 + lg * 4;
         const float4 bv = *reinterpret_cast<const float4 *>(bias + ch0);
+#ifdef HIVE_CONV_ABL_EPI
+        for (int nt = 0; nt < 9; ++nt) {
+            if (acc[mt][nt][0] != 12345.678f) continue;
+#else
 #pragma unroll
         for (int nt = 0; nt < 9; ++nt) {
+#endif
             const int pixel = nt * 16 + lr;
             const size_t o = ((size_t)b * 144 + pixel) * 256 + ch0;
             float v0 = acc[mt][nt][0] + bv.x, v1 = acc[mt][nt][1] + bv.y, v2 = acc[mt][nt][2] + bv.z,
@@ -148,13 +160,14 @@ extern "C" int hive_nn_conv3x3(const void *x, int cin, const void *w, const floa
     const __bf16 *X = (const __bf16 *)x, *Wt = (const __bf16 *)w, *R = (const __bf16 *)residual;
     __bf16 *Y = (__bf16 *)y;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)batch), block(256);
+    constexpr int NWV = HIVE_CONV_WAVES;
+    dim3 grid((unsigned)batch), block(NWV * 64);
     if (cin == 256) {
-        if (R) hipLaunchKernelGGL((conv3x3_kernel<256, true>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
-        else hipLaunchKernelGGL((conv3x3_kernel<256, false>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
+        if (R) hipLaunchKernelGGL((conv3x3_kernel<256, true, NWV>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
+        else hipLaunchKernelGGL((conv3x3_kernel<256, false, NWV>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
     } else if (cin == 56) {
-        if (R) hipLaunchKernelGGL((conv3x3_kernel<64, true>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
-        else hipLaunchKernelGGL((conv3x3_kernel<64, false>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
+        if (R) hipLaunchKernelGGL((conv3x3_kernel<64, true, NWV>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
+        else hipLaunchKernelGGL((conv3x3_kernel<64, false, NWV>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
     } else {
         return set_error(HIVE_E_ARG, "hive_nn_conv3x3: cin must be 56 or 256");
     }
