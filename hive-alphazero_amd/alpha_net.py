@@ -203,6 +203,8 @@ class InferenceNet:
         self.fc1 = (ob.fc1.weight.detach().to(dev, torch.float32), ob.fc1.bias.detach().to(dev, torch.float32))
         self.fc2 = (ob.fc2.weight.detach().to(dev, torch.float32), ob.fc2.bias.detach().to(dev, torch.float32))
         self._graphs = {}
+        import threading
+        self._lock = threading.Lock()      # capture/replay share static buffers: one caller at a time
 
     def _conv_hip(self, x, cin, w, b, res, out):
         import ctypes
@@ -248,6 +250,11 @@ class InferenceNet:
 
     @torch.no_grad()
     def __call__(self, planes_hwc):
+        with self._lock:
+            p, v = self._call_locked(planes_hwc)
+            return (p.clone(), v.clone()) if self.use_graph else (p, v)
+
+    def _call_locked(self, planes_hwc):
         B = planes_hwc.shape[0]
         if planes_hwc.dtype != self.dtype:
             planes_hwc = planes_hwc.to(self.dtype)
@@ -264,7 +271,7 @@ class InferenceNet:
                     self._forward(static_in)
             torch.cuda.current_stream(self.device).wait_stream(s)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = self._forward(static_in)
             g = (graph, static_in, out)
             self._graphs[B] = g

@@ -56,6 +56,11 @@ class HiveModelAPI:
                     result_pipes.append(pipe)
             if not data:
                 continue
-            policy_ary, value_ary = self._forward(np.stack(data))
+            try:
+                policy_ary, value_ary = self._forward(np.stack(data))
+            except Exception as exc:          # keep serving: a failed batch answers with the exception
+                for pipe in result_pipes:
+                    pipe.send(exc)
+                continue
             for pipe, p, v in zip(result_pipes, policy_ary, value_ary):
                 pipe.send((p, float(v)))

@@ -125,18 +125,20 @@ def test_uct_search_and_model_api_gpu(golden_games):
     best2, root2, _ = UCT_search(g, 16, net)             # plain ChessNet, NCHW fp32 like the reference
     assert np.array_equal(root.child_number_visits, root2.child_number_visits)
 
-    api = HiveModelAPI(inf)
-    pipes = [api.create_pipe() for _ in range(6)]
-    api.start()
     planes = []
-    for i, rec in enumerate(golden_games[1]["plies"][3:9]):
+    for rec in golden_games[1]["plies"][3:9]:
         pl = np.zeros((12, 12, 56), dtype=np.float64)
         pl.reshape(-1)[rec["planes"]] = 1.0
         pl[:, :, 31] = rec["t"]
         planes.append(pl)
-        pipes[i].send(pl)
     x = torch.from_numpy(np.stack(planes).astype(np.float32)).cuda()
     p_ref, v_ref = inf(x)
+    torch.cuda.synchronize()
+    api = HiveModelAPI(inf)
+    pipes = [api.create_pipe() for _ in range(6)]
+    api.start()
+    for i, pl in enumerate(planes):
+        pipes[i].send(pl)
     for i, pipe in enumerate(pipes):
         assert pipe.poll(30)
         p, v = pipe.recv()

