@@ -56,6 +56,7 @@ struct Smem {
     uint32_t occ[G][6];          // cells with at least one piece
     uint32_t topw[G][6];         // cells whose top piece is white
     uint32_t mask[G][HIVE_MASK_WORDS];                          // legal mask being assembled
+    uint8_t pinfo[G][24];        // per piece: stack height | stack index << 4 (0 = in hand)
     unsigned long long feat[FULL ? G : 1][FULL ? kCells : 1];   // 56 feature bits per cell
     int done;                    // waves that have delivered their destinations
 };
@@ -87,7 +88,7 @@ struct PieceInfo {
 // own == true : get_actions semantics (env_hive.py:207-285)
 // own == false: mini_black_actions semantics for an enemy piece (env_hive.py:449-485)
 __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint32_t *occ_p, const uint32_t *topw_p,
-                                                 int q, int type, bool own, bool valid)
+                                                 const uint8_t *pinfo, int q, int type, bool own, bool valid)
 {
     PieceInfo out;
     const unsigned turn = state_byte(st, 33);
@@ -97,28 +98,24 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     const unsigned c = state_byte(st, (unsigned)q);
     const bool in_hand = c >= (unsigned)kCells;
 
-    // stack height of the mover's cell and the mover's index in it (env_hive.py:213)
-    uint32_t pw[6];
-    HIVE_UNROLL for (int i = 0; i < 6; ++i) pw[i] = st[i];
-    unsigned h = 0;
-    HIVE_UNROLL for (int r = 0; r < 22; ++r) h += (((pw[r >> 2] >> ((r & 3) * 8)) & 0xFFu) == c) ? 1u : 0u;
-    const unsigned lb = state_byte(st, 22u + ((unsigned)q >> 1));
-    const unsigned lv = (q & 1) ? (lb >> 4) : (lb & 15u);
+    // stack height of the mover's cell and the mover's index in it (env_hive.py:213), from phase 0
+    const unsigned pi = pinfo[q];
+    const unsigned h = pi & 15u, lv = pi >> 4;
     const bool on_board = valid && !in_hand;
     const bool on_top = on_board && (lv + 1u == h);
     const bool stacked = h > 1u;
 
-    const bool wq = (pw[0] & 0xFFu) < (unsigned)kCells;            // white queen placed
-    const bool bq = ((pw[2] >> 24) & 0xFFu) < (unsigned)kCells;    // black queen (piece 11) placed
+    const bool wq = state_byte(st, 0u) < (unsigned)kCells;         // white queen placed
+    const bool bq = state_byte(st, 11u) < (unsigned)kCells;        // black queen (piece 11) placed
     const int nq = (wq ? 1 : 0) + (bq ? 1 : 0);
     const int first_color = wq ? 0 : 1;
     const bool stm_queen = stm == 0 ? wq : bq;
 
     const BB occ = bb_load(occ_p);
-    const BB nocc = bb_neighbours(occ);
     const BB srcbit = bb_bit(on_board ? c : 255u);
     const BB occp = (on_board && !stacked) ? bb_xor(occ, srcbit) : occ;
-    const BB nsrc = bb_neighbours(srcbit);
+    const BB nsrc = on_board ? bb_load(d_tables.nmask[c]) : bb_zero();      // the six neighbours of src
+    BB nocc;                                                                // neighbours(occ)
 
     // ---- one-hive test (move_checker.py:58-83 / env_hive.py:509-530): flood the hive without
     // the mover from one of its neighbours until every neighbour is reached or nothing grows.
@@ -130,9 +127,11 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     bool pinned = on_top && !stacked && !has_nb;    // lone piece: empty board => False
     bool act = on_top && !stacked && has_nb;
     BB reach = bb_lowest(target);
+    // two expansions per convergence test (the reductions and the loop branch cost as much as a step)
 #define HIVE_FLOOD_STEP()                                                                 \
     if (act) {                                                                            \
-        BB nx = bb_or(reach, bb_and(bb_neighbours(reach), occp));                         \
+        BB n1 = bb_or(reach, bb_and(bb_neighbours(reach), occp));                         \
+        BB nx = bb_or(n1, bb_and(bb_neighbours(n1), occp));                               \
         bool covered = !bb_any(bb_andn(target, nx));                                      \
         bool fixed = bb_eq(nx, reach);                                                    \
         reach = nx;                                                                       \
@@ -151,16 +150,19 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
         while (__any(ga || act)) {
             HIVE_FLOOD_STEP()
             if (ga) {
-                BB nx = bb_or(V, bb_and(bb_neighbours(V), Lo));
+                BB n1 = bb_or(V, bb_and(bb_neighbours(V), Lo));
+                BB nx = bb_or(n1, bb_and(bb_neighbours(n1), Lo));
                 if (bb_eq(nx, V)) ga = false;
                 V = nx;
             }
         }
+        nocc = bb_neighbours(occ);
         rule = bb_andn(bb_and(bb_andn(bb_neighbours(V), occ), L), nsrc);
     } else {
         BB S[6];
         occupancy_views(occp, S);
         SlideCtx ctx = make_slide_ctx(occp, S);
+        nocc = bb_or(ctx.nocc, nsrc);            // N(occ) = N(occ without the mover) | N(mover)
         if (type == T_QUEEN) {
             while (__any(act)) { HIVE_FLOOD_STEP() }
             rule = slide_step(ctx, srcbit);                       // pieces.py:35-44
@@ -170,7 +172,8 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
             while (__any(aa || act)) {
                 HIVE_FLOOD_STEP()
                 if (aa) {
-                    BB nx = bb_or(R, slide_step(ctx, R));
+                    BB n1 = bb_or(R, slide_step(ctx, R));
+                    BB nx = bb_or(n1, slide_step(ctx, n1));
                     if (bb_eq(nx, R)) aa = false;
                     R = nx;
                 }
@@ -325,6 +328,7 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         (&sm.topw[0][0])[i] = 0u;
     }
     for (int i = tid; i < G * HIVE_MASK_WORDS; i += nthreads) (&sm.mask[0][0])[i] = 0u;
+    for (int i = tid; i < G * 6; i += nthreads) reinterpret_cast<uint32_t *>(&sm.pinfo[0][0])[i] = 0u;
     if (FULL)
         for (int i = tid; i < G * kCells; i += nthreads) (&sm.feat[0][0])[i] = 0ull;
     if (tid == 0) sm.done = 0;
@@ -344,6 +348,7 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
             cell_word_bit(c, wi, bit);
             atomicOr(&sm.occ[b][wi], 1u << bit);
             if (lv + 1u == h && q < 11) atomicOr(&sm.topw[b][wi], 1u << bit);
+            sm.pinfo[b][q] = (uint8_t)(h | (lv << 4));
         }
     }
     __syncthreads();
@@ -358,7 +363,7 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     bool own;
     if (!FULL) { q = stm * 11 + wv; own = true; }
     else { int col = item >> 3; q = col * 11 + wv; own = (col == stm); }
-    PieceInfo pc = piece_dests(st, sm.occ[bl], sm.topw[bl], q, type, own, valid);
+    PieceInfo pc = piece_dests(st, sm.occ[bl], sm.topw[bl], sm.pinfo[bl], q, type, own, valid);
     if (own && (mask != nullptr || count != nullptr)) scatter_dests(sm.mask[bl], pc.D, wv);
 
     if (FULL) {

@@ -19,6 +19,9 @@
 #include "../../include/hive_abi.h"
 #include "../../include/hive_nn.h"
 
+#ifndef HIVE_CONV_PAD
+#define HIVE_CONV_PAD 48       // bytes added to the LDS pixel stride (bank spreading of the B-fragment reads)
+#endif
 #ifndef HIVE_CONV_WAVES
 #define HIVE_CONV_WAVES 4      // waves per board workgroup (4: 4 M tiles per wave, 2 workgroups per CU; measured faster than 8)
 #endif
@@ -35,7 +38,7 @@ __global__ void __launch_bounds__(NWAVE * 64, NWAVE / 2)
 conv3x3_kernel(const __bf16 *__restrict__ X, int cin, const __bf16 *__restrict__ W, const float *__restrict__ bias,
                const __bf16 *__restrict__ R, __bf16 *__restrict__ Y, int relu)
 {
-    constexpr int PS = CINP * 2 + 32;          // pixel stride in LDS, bytes
+    constexpr int PS = CINP * 2 + HIVE_CONV_PAD;   // pixel stride in LDS, bytes
     constexpr int KC = CINP / 32;              // 32-deep k-steps per tap
     constexpr int MT = 16 / NWAVE;             // 16-channel M tiles per wave
     constexpr int NT = NWAVE * 64;             // threads

@@ -22,7 +22,8 @@ constexpr bool straight_line(int a, int b)
 struct Tables {
     uint32_t line[kCells][6];   // bitboard of {b : straight_line(a, b)}
     uint8_t nbr[kCells][8];     // adjacent_tiles in reference order (tile.py:111-123), padded to 8
-    constexpr Tables() : line{}, nbr{}
+    uint32_t nmask[kCells][6];  // bitboard of the six neighbours of a cell
+    constexpr Tables() : line{}, nbr{}, nmask{}
     {
         for (int a = 0; a < kCells; ++a) {
             for (int b = 0; b < kCells; ++b)
@@ -41,7 +42,11 @@ struct Tables {
                     bool swap = (rj > ri) || (rj == ri && cj < ci);
                     if (swap) { int t = cand[i]; cand[i] = cand[j]; cand[j] = t; }
                 }
-            for (int i = 0; i < 6; ++i) nbr[a][i] = (uint8_t)cand[i];
+            for (int i = 0; i < 6; ++i) {
+                nbr[a][i] = (uint8_t)cand[i];
+                int row = cand[i] / 12, col = cand[i] % 12;
+                nmask[a][row >> 1] |= 1u << (((row & 1) << 4) | col);
+            }
             nbr[a][6] = 255; nbr[a][7] = 255;
         }
     }
