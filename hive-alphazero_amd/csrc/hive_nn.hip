@@ -22,6 +22,9 @@
 #ifndef HIVE_CONV_PAD
 #define HIVE_CONV_PAD 48       // bytes added to the LDS pixel stride (bank spreading of the B-fragment reads)
 #endif
+#ifndef HIVE_CONV_BDEPTH
+#define HIVE_CONV_BDEPTH 3     // LDS B-fragment reads kept in flight
+#endif
 #ifndef HIVE_CONV_WAVES
 #define HIVE_CONV_WAVES 4      // waves per board workgroup (4: 4 M tiles per wave, 2 workgroups per CU; measured faster than 8)
 #endif
@@ -114,12 +117,19 @@ conv3x3_kernel(const __bf16 *__restrict__ X, int cin, const __bf16 *__restrict__
                             A[half ^ 1][mt] = *reinterpret_cast<const bf16x8 *>(wp + (size_t)mt * 512);
                     }
                 }
+                // B fragments: keep HIVE_CONV_BDEPTH reads in flight ahead of the MFMAs that consume them
+                bf16x8 Bf[9];
+#pragma unroll
+                for (int nt = 0; nt < HIVE_CONV_BDEPTH; ++nt)
+                    Bf[nt] = *reinterpret_cast<const bf16x8 *>(lds + boff[nt] + kc * 64);
 #pragma unroll
                 for (int nt = 0; nt < 9; ++nt) {
-                    const bf16x8 Bf = *reinterpret_cast<const bf16x8 *>(lds + boff[nt] + kc * 64);
+                    if (nt + HIVE_CONV_BDEPTH < 9)
+                        Bf[nt + HIVE_CONV_BDEPTH] =
+                            *reinterpret_cast<const bf16x8 *>(lds + boff[nt + HIVE_CONV_BDEPTH] + kc * 64);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[half][mt], Bf, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[half][mt], Bf[nt], acc[mt][nt], 0, 0, 0);
                 }
             }
         }

@@ -145,3 +145,34 @@ def test_uct_search_and_model_api_gpu(golden_games):
         assert isinstance(v, float) and p.shape == (1584,)
         assert np.allclose(p, p_ref[i].cpu().numpy(), atol=1e-5) and abs(v - float(v_ref[i])) < 1e-4
     api.stop()
+
+
+def test_search_with_inflight_slots_virtual_loss():
+    """BASELINE config 5 shape: several leaves in flight per tree (virtual loss keeps them apart);
+    every simulation is accounted for and the chosen moves stay legal."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd import batch, mcts, packing, playout
+    G, sims, slots = 48, 41, 4
+    boards = playout.random_positions(G, seed=9)
+    B = batch.BoardBatch(G)
+    B.import_state(boards)
+    rb, rh = B.export_state()
+    ts = mcts.TreeSearch(G, sims, _host_stub_evaluator, plane_dtype=torch.float32, seed=5, slots=slots)
+    action, policy, sum_n = ts.search(rb, rh)
+    torch.cuda.synchronize()
+    over, _ = B.terminal()
+    mask, _, _ = B.legal()
+    m = mask.cpu().numpy().view(np.uint32)
+    st = packing.unpack_boards(rb.cpu().numpy())
+    nodes = ts.node_counts().cpu().numpy()
+    for g in range(G):
+        if over[g].item() or st["turn"][g] >= 55:
+            continue
+        legal = packing.mask_to_actions(m[g])
+        assert (action[g].item() in legal) if legal else action[g].item() == -1
+        # collisions give their virtual loss back, so visits <= sims - 1 and every visit is a real backup
+        assert 0 < sum_n[g].item() <= sims - 1
+        assert nodes[g] <= sims and nodes[g] <= ts.max_nodes
+        pol = policy[g].cpu().numpy()
+        assert set(np.nonzero(pol)[0]).issubset(set(legal))
+    ts.close(); B.close()
