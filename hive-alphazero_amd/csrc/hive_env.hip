@@ -29,8 +29,23 @@
 namespace hive {
 
 __device__ const Tables d_tables = kTables;
+#ifdef HIVE_DBG_ITERS
+__device__ unsigned long long d_iters[32];
+__device__ unsigned long long d_stamps[11][8];
+#define HIVE_STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x % 16 == 0) atomicAdd(&d_stamps[wv][i], (unsigned long long)(clock64() - t_start)); } while (0)
+#else
+#define HIVE_STAMP(i) do { } while (0)
+#endif
+#ifdef HIVE_DBG_ITERS
+#define HIVE_COUNT_ITER() do { ++dbg_it; } while (0)
+#else
+#define HIVE_COUNT_ITER() do { } while (0)
+#endif
 
 constexpr int NW = 11;                 // waves per workgroup = piece slots per colour
+#ifndef HIVE_PIECE_WPE
+#define HIVE_PIECE_WPE 7                // waves per SIMD asked of the register allocator (72 VGPRs; measured best)
+#endif
 constexpr unsigned kHand = 255u;
 
 enum PieceType { T_QUEEN = 0, T_BEETLE = 1, T_SPIDER = 2, T_GRASS = 3, T_ANT = 4 };
@@ -50,13 +65,14 @@ __device__ __forceinline__ int slot_group_start(int slot)
 // FULL = true : 8 boards per workgroup, quads 0-7 = white piece, 8-15 = black piece of slot
 // `wave` (both colours are needed by the planes).
 template <bool FULL>
-struct Smem {
+struct alignas(16) Smem {
     static constexpr int G = FULL ? 8 : 16;
     uint32_t state[G][16];       // HiveBoard records
     uint32_t occ[G][6];          // cells with at least one piece
     uint32_t topw[G][6];         // cells whose top piece is white
     uint32_t mask[G][HIVE_MASK_WORDS];                          // legal mask being assembled
     uint8_t pinfo[G][24];        // per piece: stack height | stack index << 4 (0 = in hand)
+    int32_t nlegal[G];           // legal-move count being accumulated
     unsigned long long feat[FULL ? G : 1][FULL ? kCells : 1];   // 56 feature bits per cell
     int done;                    // waves that have delivered their destinations
 };
@@ -122,6 +138,7 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     // The piece's own flood (Ant reach, Grasshopper line flood, Spider first steps) runs in the
     // SAME loop, speculatively for every top piece: two independent dependency chains per
     // iteration, and the trip count is the max of the two floods instead of their sum.
+    int dbg_it = 0; (void)dbg_it;
     BB target = bb_and(nsrc, occp);
     const bool has_nb = bb_any(target);
     bool pinned = on_top && !stacked && !has_nb;    // lone piece: empty board => False
@@ -148,6 +165,7 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
         BB V = srcbit;
         bool ga = on_top;
         while (__any(ga || act)) {
+            HIVE_COUNT_ITER();
             HIVE_FLOOD_STEP()
             if (ga) {
                 BB n1 = bb_or(V, bb_and(bb_neighbours(V), Lo));
@@ -164,12 +182,13 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
         SlideCtx ctx = make_slide_ctx(occp, S);
         nocc = bb_or(ctx.nocc, nsrc);            // N(occ) = N(occ without the mover) | N(mover)
         if (type == T_QUEEN) {
-            while (__any(act)) { HIVE_FLOOD_STEP() }
+            while (__any(act)) { HIVE_COUNT_ITER(); HIVE_FLOOD_STEP() }
             rule = slide_step(ctx, srcbit);                       // pieces.py:35-44
         } else if (type == T_ANT) {
             BB R = srcbit;                                        // pieces.py:59-63, move_checker.py:217-246
             bool aa = on_top;
             while (__any(aa || act)) {
+                HIVE_COUNT_ITER();
                 HIVE_FLOOD_STEP()
                 if (aa) {
                     BB n1 = bb_or(R, slide_step(ctx, R));
@@ -190,6 +209,7 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 BB acc = bb_zero();
                 bool sa = on_top && bb_any(A);
                 while (__any(sa || act)) {
+                    HIVE_COUNT_ITER();
                     HIVE_FLOOD_STEP()
                     if (sa) {
                         BB a = bb_lowest(A);
@@ -205,7 +225,7 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 rule = bb_andn(acc, veto);
             } else {
                 // Beetle, pieces.py:100-113 + move_checker.py:201-209
-                while (__any(act)) { HIVE_FLOOD_STEP() }
+                while (__any(act)) { HIVE_COUNT_ITER(); HIVE_FLOOD_STEP() }
                 BB Q1 = slide_raw(ctx, srcbit);
                 BB Q0 = shift_dirs(bb_andn(bb_andn(srcbit, ctx.cs[0]), b0), bb_andn(bb_andn(srcbit, ctx.cs[1]), b1),
                                    bb_andn(bb_andn(srcbit, ctx.cs[2]), b2), bb_andn(bb_andn(srcbit, ctx.cs[3]), b3),
@@ -216,6 +236,9 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
         }
     }
 #undef HIVE_FLOOD_STEP
+#ifdef HIVE_DBG_ITERS
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&d_iters[type], (unsigned long long)dbg_it); atomicAdd(&d_iters[8 + type], 1ull); }
+#endif
     const bool movable = on_top && !pinned;
 
     // ---- next_move_tiles (env_hive.py:66-69,150-161)
@@ -298,7 +321,7 @@ __device__ __forceinline__ void scatter_dests(uint32_t *mrow, BB D, int slot)
 // There is no barrier after the piece work: each wave ORs its results into LDS and leaves; the
 // last wave to finish writes the workgroup's boards out.
 template <bool FULL>
-__global__ void __launch_bounds__(NW * 64)
+__global__ void __launch_bounds__(NW * 64, HIVE_PIECE_WPE)
 hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restrict__ mask,
                   int32_t *__restrict__ count, unsigned long long *__restrict__ feat)
 {
@@ -311,6 +334,9 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nthreads = NW * 64;
     const long long gbase = (long long)blockIdx.x * G;
+#ifdef HIVE_DBG_ITERS
+    const long long t_start = clock64();
+#endif
 
     // ---------------- phase 0: stage records, clear accumulators
     for (int i = tid; i < G * 4; i += nthreads) {
@@ -332,6 +358,7 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     if (FULL)
         for (int i = tid; i < G * kCells; i += nthreads) (&sm.feat[0][0])[i] = 0ull;
     if (tid == 0) sm.done = 0;
+    if (tid < G) sm.nlegal[tid] = 0;
     __syncthreads();
 
     // occupancy and top-colour boards: every (board, piece) pair ORs its bit in
@@ -353,6 +380,7 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     }
     __syncthreads();
 
+    HIVE_STAMP(0);
     // ---------------- phase 1: one quad per (board, piece), one piece slot per wave
     const bool valid = gbase + bl < n;
     const uint32_t *st = sm.state[bl];
@@ -364,7 +392,13 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     if (!FULL) { q = stm * 11 + wv; own = true; }
     else { int col = item >> 3; q = col * 11 + wv; own = (col == stm); }
     PieceInfo pc = piece_dests(st, sm.occ[bl], sm.topw[bl], sm.pinfo[bl], q, type, own, valid);
-    if (own && (mask != nullptr || count != nullptr)) scatter_dests(sm.mask[bl], pc.D, wv);
+    HIVE_STAMP(1);
+    if (own && (mask != nullptr || count != nullptr)) {
+        scatter_dests(sm.mask[bl], pc.D, wv);
+        const int nd = __popc(pc.D.lo) + __popc(pc.D.hi);       // destination sets of different pieces are disjoint
+        if (nd) atomicAdd(&sm.nlegal[bl], nd);
+    }
+    HIVE_STAMP(2);
 
     if (FULL) {
         // ---------------- per-piece feature bits (env_hive.py:352-429)
@@ -419,20 +453,16 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     const int nb = (int)((n - gbase) < G ? (n - gbase) : G);
-    if (mask != nullptr)
-        for (int i = lane; i < nb * HIVE_MASK_WORDS; i += 64) mask[gbase * HIVE_MASK_WORDS + i] = (&sm.mask[0][0])[i];
-    if (count != nullptr) {
-        // 4 lanes per board sum the popcounts of its 50 words
-        for (int b0 = 0; b0 < G; b0 += 16) {
-            int b = b0 + (lane >> 2), l4 = lane & 3;
-            uint32_t c = 0;
-            if (b < G)
-                for (int w = l4; w < HIVE_MASK_WORDS; w += 4) c += (uint32_t)__popc(sm.mask[b][w]);
-            c += quad<kQuadSwap1>(c);
-            c += quad<kQuadSwap2>(c);
-            if (b < nb && l4 == 0) count[gbase + b] = (int32_t)c;
-        }
+    if (mask != nullptr) {
+        // G boards x 200 bytes are one contiguous, 16-byte aligned block on both sides
+        const uint4 *src = reinterpret_cast<const uint4 *>(&sm.mask[0][0]);
+        uint4 *dst = reinterpret_cast<uint4 *>(mask + gbase * HIVE_MASK_WORDS);
+        const int n16 = nb * HIVE_MASK_WORDS / 4, rem = nb * HIVE_MASK_WORDS - n16 * 4;
+        for (int i = lane; i < n16; i += 64) dst[i] = src[i];
+        if (lane < rem) mask[gbase * HIVE_MASK_WORDS + n16 * 4 + lane] = (&sm.mask[0][0])[n16 * 4 + lane];
     }
+    if (count != nullptr && lane < nb) count[gbase + lane] = sm.nlegal[lane];
+    HIVE_STAMP(3);
     if (FULL && feat != nullptr) {
         const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(&sm.feat[0][0]);
         ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(feat + gbase * kCells);
@@ -900,6 +930,19 @@ int hive_batch_import(HiveBatch *h, const HiveBoard *boards, const HiveHistory *
     h->legal_valid = false;
     return HIVE_OK;
 }
+
+#ifdef HIVE_DBG_ITERS
+int hive_debug_iters(unsigned long long *host16)
+{
+    HIP_TRY(hipMemcpyFromSymbol(host16, HIP_SYMBOL(hive::d_iters), sizeof(unsigned long long) * 16));
+    return HIVE_OK;
+}
+int hive_debug_stamps(unsigned long long *host88)
+{
+    HIP_TRY(hipMemcpyFromSymbol(host88, HIP_SYMBOL(hive::d_stamps), sizeof(unsigned long long) * 88));
+    return HIVE_OK;
+}
+#endif
 
 // test hook (not in hive_abi.h's product surface): copy the device tables to device buffers
 int hive_debug_tables(uint32_t *line /* [144*6] */, uint8_t *nbr /* [144*8] */, void *stream)

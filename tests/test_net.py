@@ -81,7 +81,9 @@ def test_inference_net_gpu_tolerances():
         _check(p2, v2, gold, atol_p, atol_v)                    # stated tolerance of the reduced-precision engine
         p3, v3 = inf(x)                                         # graph replay: same result up to the library
         # MIOpen / hipBLASLt use split-K float atomics: repeated runs differ in the last bits (measured <= 2e-6)
-        assert torch.allclose(p2, p3, atol=1e-5) and torch.allclose(v2, v3, atol=1e-3)
+        dp, dv = float((p2 - p3).abs().max()), float((v2 - v3).abs().max())
+        # the policy logits leave the bf16/fp16 GEMM rounded to 8/11 bits; a split-K reordering can flip the last one
+        assert dp <= (1e-6 if dt == torch.float32 else 1e-4) and dv <= 1e-3, (str(dt), dp, dv)
 
 
 @pytest.mark.gpu
