@@ -86,7 +86,42 @@ def selfplay_measure(args, local_rank, world):
         "results": {"white": sp.white_wins, "black": sp.black_wins, "draw_or_cap": sp.draws},
     }
     sp.close()
+    if args.cpu_baseline_selfplay and int(os.environ.get("RANK", "0")) == 0:
+        out["cpu_baseline"] = selfplay_cpu_baseline(args.sims)
     return out
+
+
+def selfplay_cpu_baseline(sims, plies=30):
+    """The reference's process model on ONE host core: sequential HivePlayer (hive_alphazero_amd.solo_play, pinned
+    bit-exact to woker/solo_play.py) over the CPU oracle env, with a stub evaluator -- i.e. env + tree only, the
+    network cost is EXCLUDED (the reference ran it on a separate GPU thread).  A bounded sample of `plies` moves."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hive_alphazero_amd.solo_play as sp
+    from mcts_stub import StubPipe
+    from oracle_env import OracleGamePlay
+    sp.SEARCH_THREADS = 1
+    np.random.seed(0)
+    g = OracleGamePlay()
+    rng = np.random.default_rng(0)
+    for _ in range(8):
+        acts = g.actions()
+        g.move(int(acts[rng.integers(len(acts))]))
+    player = sp.HivePlayer(pipes=[StubPipe()])
+    player.simulation_num_per_move = sims
+    t0 = time.perf_counter()
+    done = 0
+    for _ in range(plies):
+        if g.game_is_over() or g.state.turn >= 55:
+            break
+        a, _ = player.action(g)
+        g.move(a)
+        done += 1
+    el = time.perf_counter() - t0
+    plies = max(done, 1)
+    return {"value": round(60.0 / (el / plies * 54.0), 4), "unit": "games/min", "cores": 1, "kind": "port",
+            "sample": f"{plies} searched plies at {sims} sims from ply 8, sequential HivePlayer mirror + C oracle env, "
+                      "stub evaluator (network cost excluded), extrapolated to 54-ply games"}
 
 
 def main():
@@ -101,6 +136,7 @@ def main():
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--selfplay-plies", type=int, default=6, help="timed plies of the self-play side measurement (0 = skip)")
     ap.add_argument("--selfplay-warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline-selfplay", dest="cpu_baseline_selfplay", action="store_false")
     args = ap.parse_args()
 
     import numpy as np
