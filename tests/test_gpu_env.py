@@ -253,3 +253,54 @@ def test_random_playout_vs_oracle_lockstep(hv):
         B.step(acts, sync=True)
     assert done.all()
     B.close()
+
+
+def test_size_independent_properties_large_batch(hv):
+    """65,536 boards (16x the bench batch): count == popcount(mask), sorted strictly increasing lists that
+    agree with the mask, idempotence, and permutation invariance of the batch."""
+    h, batch, packing = hv
+    from hive_alphazero_amd import playout
+    base = playout.random_positions(4096, seed=77)
+    perm = torch.randperm(65536, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    big = base.repeat(16, 1)[perm].contiguous()
+    mask, count, lst = batch.movegen(big, want_list=True)
+    mask2, count2, _ = batch.movegen(big)
+    assert torch.equal(mask, mask2) and torch.equal(count, count2)                     # idempotent
+    m0, c0, _ = batch.movegen(base)
+    assert torch.equal(mask, m0.repeat(16, 1)[perm]) and torch.equal(count, c0.repeat(16)[perm])   # permutation invariant
+    bits = mask.view(torch.uint8)
+    pop = torch.zeros_like(count)
+    for sh in range(8):
+        pop += ((bits >> sh) & 1).sum(dim=1).to(torch.int32)
+    assert torch.equal(pop, count)
+    l = lst.to(torch.int32)
+    valid = torch.arange(256, device="cuda").view(1, -1) < count.view(-1, 1)
+    assert bool(((l >= 0) == valid).all())
+    inc = (l[:, 1:] > l[:, :-1]) | ~valid[:, 1:]
+    assert bool(inc.all())
+    idx = torch.where(valid, l, torch.zeros_like(l)).long()
+    word = mask.gather(1, idx >> 5)
+    assert bool(((((word >> (idx & 31)) & 1) == 1) | ~valid).all())
+
+
+def test_abi_argument_errors(hv):
+    h, batch, packing = hv
+    import ctypes
+    L = h.load()
+    hd = ctypes.c_void_p()
+    assert L.hive_batch_create(0, 0, ctypes.byref(hd)) == -1                 # empty batch
+    assert L.hive_batch_create(4, 99, ctypes.byref(hd)) == -1                # bad device
+    assert L.hive_movegen_launch(None, 4, None, None, None, None) == -1      # NULL boards
+    b = torch.zeros((4, 64), dtype=torch.uint8, device="cuda")
+    lst = torch.zeros((4, 256), dtype=torch.int16, device="cuda")
+    assert L.hive_movegen_launch(ctypes.c_void_p(b.data_ptr()), 4, None, None, ctypes.c_void_p(lst.data_ptr()), None) == -1
+    assert b"mask" in L.hive_last_error()
+    B = batch.BoardBatch(2)
+    pl = torch.zeros((2, 12, 12, 56), dtype=torch.float32, device="cuda")
+    assert L.hive_batch_encode(B._h, ctypes.c_void_p(pl.data_ptr()), 7, 0) == -1    # unknown dtype
+    # a fresh game: five placements on the start tile, planes all-zero except the turn plane
+    mask, count, _ = B.legal()
+    assert count.tolist() == [5, 5]
+    pl = B.encode(torch.float32, "hwc")
+    assert float(pl[..., 31].min()) == 1.0 and float(pl.sum()) == 2 * 144.0
+    B.close()
