@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--selfplay-plies", type=int, default=6, help="timed plies of the self-play side measurement (0 = skip)")
     ap.add_argument("--selfplay-warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline-selfplay", dest="cpu_baseline_selfplay", action="store_false")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
+                    "the multi-rank path on a single GPU")
     args = ap.parse_args()
 
     import numpy as np
@@ -148,9 +150,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: hive_alphazero_amd has no CPU path")
+    local_rank = local_rank % torch.cuda.device_count()          # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     import hive_alphazero_amd as h
     from hive_alphazero_amd import playout
@@ -192,6 +198,29 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     wall_max = float(tt.item())
     mean_legal = float(count.float().mean().item())
+
+    # side measurement: the same 4096-board steps, independent batches issued round-robin on 4 HIP streams
+    # (what a self-play engine with several game groups does); NOT the headline value
+    overlapped = None
+    if rank == 0:
+        streams = [torch.cuda.Stream() for _ in range(4)]
+        outs = [(torch.empty_like(mask), torch.empty_like(count)) for _ in streams]
+        torch.cuda.synchronize()
+        def ostep(i):
+            st = streams[i % 4]
+            m, c = outs[i % 4]
+            L.hive_movegen_launch(bp, n, ctypes.c_void_p(m.data_ptr()), ctypes.c_void_p(c.data_ptr()), None,
+                                  ctypes.c_void_p(st.cuda_stream))
+        for i in range(16):
+            ostep(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            ostep(i)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        overlapped = {"streams": 4, "Mboards_per_s": round(n * args.steps / el / 1e6, 2),
+                      "ms_per_step": round(el * 1e3 / args.steps, 6)}
 
     # side measurement: the same kernel on a batch large enough to fill all 256 CUs
     sat = None
@@ -249,6 +278,7 @@ def main():
                          "kernel": "hive_piece_kernel<false>", "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_BOARD,
                          "note": "VALU-issue bound: 4096 boards = 256 workgroups x 11 waves, ~2.75 waves per SIMD; see saturated"},
+            "overlapped_4_streams": overlapped,
             "saturated": sat,
             "selfplay": selfplay,
         }
