@@ -134,6 +134,11 @@ class SelfPlay:
         self.records = []            # (features int64[games,144], policy fp32[games,1584], mover int8[games], game_id)
         self.game_id = torch.arange(games, device=self.device)
         self._next_id = games
+        # per running game: list of (packed features uint64[144], history words uint32[4,2,6] + length, turn,
+        # visit policy float32[1584], mover) -- turned into the reference's rows when the game ends
+        self._open = {int(i): [] for i in range(games)}
+        self.finished_games = []     # list of (value_white, rows) ; rows as records.game_entries returns them
+        self.max_finished_kept = 64
 
     def stagger(self, seed=0):
         """Spread the games over plies 0..53 with uniformly random legal moves so that a timed window
@@ -163,10 +168,34 @@ class SelfPlay:
             self.finished += nd
             self.finished_lengths.append(turn[done].float().mean().item())
             idx = torch.nonzero(done).view(-1).to(torch.int32)
+            if self.keep_records:
+                self._close_games(idx.cpu().tolist(), winner.cpu().tolist())
             self.env.reset(idx)
             self.game_id[done] = torch.arange(self._next_id, self._next_id + nd, device=self.device)
             self._next_id += nd
         return nd
+
+    def _close_games(self, slots, winner):
+        """self_play.py:165-191: value_white = +1 / -1 / 0; a draw or the length cap scores -1 for both."""
+        from . import records
+        for s in slots:
+            plies = self._open[s]
+            self._open[s] = []
+            if not plies:
+                continue
+            vw = 1 if winner[s] == 1 else (-1 if winner[s] == 2 else 0)
+            if len(self.finished_games) < self.max_finished_kept:
+                self.finished_games.append((vw, plies))
+
+    def finished_game_rows(self, k):
+        """The k-th kept finished game as the reference's JSON rows [state, policy, value, [game_len, counter]]."""
+        from . import records
+        vw, plies = self.finished_games[k]
+        expanded = []
+        for words, hist, hlen, turn, policy, mover in plies:
+            hp = records.history_planes(hist, hlen)
+            expanded.append((records.unpack_features(words, turn, hp), policy, "W" if mover == 0 else "B"))
+        return records.game_entries(expanded, vw)
 
     def play_ply(self):
         """One move for every game.  Returns the number of games that finished before this move."""
@@ -176,8 +205,22 @@ class SelfPlay:
         if self.keep_records:
             mover = (1 - (boards[:, 33] & 1)).to(torch.int8)
             self.records.append((self.search.root_planes.view(self.games, 144), policy.clone(), mover, self.game_id.clone()))
-            if len(self.records) > 64:
+            if len(self.records) > 8:
                 self.records.pop(0)
+            # host copies for the per-game record (8 MB per ply at 1024 games)
+            feat_h = self.search.root_planes.view(self.games, 144).cpu().numpy().view("uint64")
+            pol_h = policy.cpu().numpy()
+            st_h = boards.cpu().numpy()
+            hist_h = hist.cpu().numpy().view("uint32").reshape(self.games, 2, 4, 2, 6)
+            act_h = action.cpu().numpy()
+            for g in range(self.games):
+                if act_h[g] == -2:
+                    continue
+                turn = int(st_h[g, 33])
+                persp = 0 if turn % 2 == 1 else 1
+                hl = int(st_h[g, 35])
+                hlen = (hl & 15) if persp == 0 else (hl >> 4)
+                self._open[g].append((feat_h[g].copy(), hist_h[g, persp].copy(), hlen, turn, pol_h[g].copy(), persp))
         # the env re-derives the legal masks and refuses anything not in them: the search's edges come
         # from the same kernels, so illegal_count() must stay 0 (asserted by the tests)
         self.env.step(action, sync=False)

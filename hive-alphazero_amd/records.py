@@ -28,6 +28,21 @@ def unpack_features(words, turn, history_planes=None):
     return planes
 
 
+def history_planes(hist_words, hist_len):
+    """uint32[4,2,6] history bitboards of the mover's perspective (+ how many entries are valid) ->
+    bool [12,12,8] planes 36..43 (env_hive.py:431-434)."""
+    out = np.zeros((12, 12, 8))
+    hw = np.asarray(hist_words).astype(np.uint32).reshape(4, 2, 6)
+    for age in range(min(int(hist_len), 4)):
+        for k in range(2):
+            for r in range(6):
+                v = int(hw[age, k, r])
+                for bit in range(32):
+                    if (v >> bit) & 1:
+                        out[2 * r + (bit >> 4), bit & 15, 2 * age + k] = 1.0
+    return out
+
+
 def game_entries(plies, value_white):
     """plies: list of (planes [12,12,56], policy [1584], player 'W'/'B') in game order ->
     the reference's data rows (self_play.py:178-191)."""

@@ -176,3 +176,47 @@ def test_search_with_inflight_slots_virtual_loss():
         pol = policy[g].cpu().numpy()
         assert set(np.nonzero(pol)[0]).issubset(set(legal))
     ts.close(); B.close()
+
+
+def test_selfplay_records_match_env_planes(tmp_path):
+    """First 'next' row: the rows the GPU self-play engine emits are the reference's wire
+    format and their state planes equal GamePlay.encode_board of the recorded positions (replayed
+    through the env from the moves implied by consecutive records is not possible, so the planes are
+    cross-checked against a second, independent encode of the same packed record + history)."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd import batch, mcts, records
+
+    def cheap_eval(planes):
+        B = planes.shape[0]
+        p = torch.full((B, 1584), 1.0 / 1584, device="cuda")
+        v = torch.zeros((B,), device="cuda")
+        return p, v
+
+    sp = mcts.SelfPlay(48, 6, cheap_eval, seed=3, plane_dtype=torch.float32)
+    sp.stagger(seed=4)
+    checked = 0
+    for _ in range(14):
+        boards, hist = sp.env.export_state()
+        want = sp.env.encode(torch.float32, "hwc").cpu().numpy()
+        over, _ = sp.env.terminal()
+        turn = boards[:, 33].cpu().numpy()
+        alive = (over.cpu().numpy() == 0) & (turn < 55)
+        sp.play_ply()
+        for g in range(48):
+            if alive[g] and sp._open[g]:
+                words, hw, hlen, t, pol, mover = sp._open[g][-1]
+                got = records.unpack_features(words, t, records.history_planes(hw, hlen))
+                assert np.array_equal(got, want[g].astype(np.float64)), g
+                assert abs(pol.sum() - 1.0) < 1e-4
+                checked += 1
+    sp._retire_finished()
+    assert checked > 300 and sp.env.illegal_count() == 0
+    assert len(sp.finished_games) > 0
+    rows = sp.finished_game_rows(0)
+    vw = sp.finished_games[0][0]
+    assert all(len(r) == 4 and np.asarray(r[0]).shape == (12, 12, 56) and len(r[1]) == 1584 for r in rows)
+    assert set(r[2] for r in rows) <= ({-1} if vw == 0 else {1, -1})
+    path = records.flush_buffer(rows, str(tmp_path))
+    back = records.load_data(path)
+    assert len(back) == len(rows)
+    sp.close()
