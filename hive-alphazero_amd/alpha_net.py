@@ -135,6 +135,49 @@ def train(net, dataset, epoch_start=0, epoch_stop=10, cpu=0, batch_size=512, lr=
     return losses_per_epoch
 
 
+class Trainer:
+    """Training step of alpha_net.py:117-162 laid out for MI355X (second "next" row):
+    channels-last activations, bf16 autocast on the MFMA units with fp32 master weights and fp32
+    loss, Adam lr 1e-3 + MultiStepLR like the reference.  With torch.distributed initialised the
+    model is wrapped in DistributedDataParallel (gradient all-reduce over RCCL/xGMI, bucketed and
+    overlapped with backward by DDP); self-play itself never needs a collective."""
+
+    def __init__(self, net, lr=0.001, autocast_dtype=torch.bfloat16, ddp=None):
+        import torch.distributed as dist
+        self.device = next(net.parameters()).device
+        self.net = net.to(memory_format=torch.channels_last)
+        self.autocast_dtype = autocast_dtype if self.device.type == "cuda" else None
+        use_ddp = ddp if ddp is not None else (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        self.model = self.net
+        if use_ddp:
+            ids = [self.device.index] if self.device.type == "cuda" else None
+            self.model = torch.nn.parallel.DistributedDataParallel(self.net, device_ids=ids, bucket_cap_mb=64)
+        self.criterion = AlphaLoss()
+        self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr)
+        self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=[100, 200, 300, 400], gamma=0.2)
+
+    def loss(self, state_nchw, policy, value):
+        x = state_nchw.to(self.device).float().contiguous(memory_format=torch.channels_last)
+        policy, value = policy.to(self.device).float(), value.to(self.device).float()
+        if self.autocast_dtype is not None:
+            with torch.autocast("cuda", dtype=self.autocast_dtype):
+                p, v = self.model(x)
+        else:
+            p, v = self.model(x)
+        return self.criterion(v.float()[:, 0], value, p.float(), policy)
+
+    def step(self, state_nchw, policy, value):
+        self.model.train()
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.loss(state_nchw, policy, value)
+        loss.backward()
+        self.optimizer.step()
+        return float(loss.detach())
+
+    def end_epoch(self):
+        self.scheduler.step()
+
+
 def _fold(conv, bn):
     """eval-mode BatchNorm folded into the preceding convolution (fp32 math)."""
     w = conv.weight.detach().float()

@@ -46,14 +46,20 @@ class HiveModelAPI:
 
     def _predict_batch_worker(self):
         while self._running:
-            ready = connection.wait(self.pipes, timeout=0.05)
+            try:
+                ready = connection.wait(self.pipes, timeout=0.05)
+            except (OSError, EOFError, ValueError):      # the clients closed their ends: stop serving
+                return
             if not ready:
                 continue
             data, result_pipes = [], []
-            for pipe in ready:
-                while pipe.poll():
-                    data.append(np.asarray(pipe.recv(), dtype=np.float32))
-                    result_pipes.append(pipe)
+            try:
+                for pipe in ready:
+                    while pipe.poll():
+                        data.append(np.asarray(pipe.recv(), dtype=np.float32))
+                        result_pipes.append(pipe)
+            except (OSError, EOFError):
+                return
             if not data:
                 continue
             try:

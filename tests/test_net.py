@@ -139,3 +139,50 @@ def test_inference_net_hip_vs_torch_backend():
     pb, vb = b(x)
     _check(pa, va, gold, 2e-4, 3e-2)
     assert float((pa - pb).abs().max()) < 2e-4 and float((va - vb).abs().max()) < 3e-2
+
+
+def _toy_batch(n=8, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand((n, 56, 12, 12), generator=g) < 0.05).float()
+    x[:, 31] = 9.0
+    pol = torch.zeros((n, 1584))
+    pol[torch.arange(n), torch.randint(0, 1584, (n,), generator=g)] = 1.0
+    val = torch.where(torch.rand((n,), generator=g) < 0.5, -1.0, 1.0)
+    return x, pol, val
+
+
+def test_trainer_loss_matches_reference_formula_cpu():
+    """AlphaLoss = (v - z)^2 + sum(-pi * log(1e-6 + p)) (alpha_net.py:98-115); one Adam step lowers it."""
+    from hive_alphazero_amd.alpha_net import ChessNet, Trainer
+    torch.manual_seed(1)
+    net = ChessNet()
+    tr = Trainer(net)
+    x, pol, val = _toy_batch(4)
+    net.eval()
+    with torch.no_grad():
+        p, v = net(x)
+        want = ((v[:, 0] - val) ** 2 + torch.sum(-pol * torch.log(1e-6 + p), 1)).mean()
+        got = tr.loss(x, pol, val)
+    assert abs(float(want) - float(got)) < 1e-5
+    l0 = tr.step(x, pol, val)
+    l1 = tr.step(x, pol, val)
+    assert l1 < l0
+
+
+@pytest.mark.gpu
+def test_trainer_bf16_autocast_close_to_fp32():
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.alpha_net import ChessNet, Trainer
+    torch.manual_seed(1)
+    net = ChessNet().cuda()
+    x, pol, val = _toy_batch(16)
+    net.eval()
+    fp32 = Trainer(net, autocast_dtype=None)
+    bf16 = Trainer(net, autocast_dtype=torch.bfloat16)
+    with torch.no_grad():
+        a, b = float(fp32.loss(x, pol, val)), float(bf16.loss(x, pol, val))
+    assert abs(a - b) < 0.05 * abs(a) + 0.05        # stated tolerance of the bf16 forward on the loss
+    l0 = bf16.step(x, pol, val)
+    for _ in range(3):
+        l1 = bf16.step(x, pol, val)
+    assert l1 < l0
