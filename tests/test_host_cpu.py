@@ -22,7 +22,7 @@ def test_abi_library_exports_every_declared_symbol():
     h.build()
     L = h.load()
     declared = []
-    for hdr in ("hive_abi.h", "hive_search.h"):
+    for hdr in ("hive_abi.h", "hive_search.h", "hive_nn.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         declared += re.findall(r"\b(hive_[a-z_0-9]+)\s*\(", text)
