@@ -222,7 +222,7 @@ def test_random_playout_vs_oracle_lockstep(hv):
     (legal sets, planes, terminal flags), including passes and finished games."""
     h, batch, packing = hv
     from oracle import oracle_py as O
-    n = 256
+    n = 256 * (8 if os.environ.get("HIVE_TEST_HEAVY") else 1)
     rng = np.random.default_rng(7)
     B = batch.BoardBatch(n)
     games = [O.OracleGame() for _ in range(n)]
