@@ -214,6 +214,7 @@ class InferenceNet:
         if conv == "hip" and not (dev.type == "cuda" and dtype == torch.bfloat16):
             raise ValueError("the HIP convolution path is bf16 on a GPU")
         self.conv = conv
+        self.fuse_blocks = True          # hive_nn_resblock: both convolutions of a residual block in one launch
         net = net.eval()
         cl = torch.channels_last
         if conv == "hip":
@@ -265,10 +266,20 @@ class InferenceNet:
         bufs = [torch.empty((B, 12, 12, 256), dtype=torch.bfloat16, device=self.device) for _ in range(3)]
         s = self._conv_hip(x_hwc, 56, self.h_stem[0], self.h_stem[1], None, bufs[0])
         cur = 0
+        import ctypes
+        from ._lib import check
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         for w1, b1, w2, b2 in self.h_blocks:
-            o = self._conv_hip(s, 256, w1, b1, None, bufs[(cur + 1) % 3])
-            s2 = self._conv_hip(o, 256, w2, b2, s, bufs[(cur + 2) % 3])      # relu(conv + bias + skip)
-            s, cur = s2, (cur + 2) % 3
+            if self.fuse_blocks:
+                s2 = bufs[(cur + 1) % 3]                                     # whole residual block in one launch
+                check(self._L.hive_nn_resblock(ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(w1.data_ptr()),
+                                               ctypes.c_void_p(b1.data_ptr()), ctypes.c_void_p(w2.data_ptr()),
+                                               ctypes.c_void_p(b2.data_ptr()), ctypes.c_void_p(s2.data_ptr()), B, st))
+                s, cur = s2, (cur + 1) % 3
+            else:
+                o = self._conv_hip(s, 256, w1, b1, None, bufs[(cur + 1) % 3])
+                s2 = self._conv_hip(o, 256, w2, b2, s, bufs[(cur + 2) % 3])  # relu(conv + bias + skip)
+                s, cur = s2, (cur + 2) % 3
         return s.permute(0, 3, 1, 2)             # NCHW view with channels-last strides
 
     def _forward(self, x_hwc):

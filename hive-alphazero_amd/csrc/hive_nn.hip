@@ -162,6 +162,128 @@ conv3x3_kernel(const __bf16 *__restrict__ X, int cin, const __bf16 *__restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// One residual block in one launch:  y = relu(conv2(relu(conv1(x) + b1)) + b2 + x)   (alpha_net.py:36-54)
+// The intermediate activation never leaves the CU: after conv1 its bf16 result overwrites the
+// board in LDS (all waves have finished reading x by then), conv2 reads it from there, and the
+// skip connection re-reads x from global memory (L2 / Infinity-Cache resident: it was fetched by
+// this very workgroup microseconds earlier).  Per block this removes one 75 MB write and one
+// 75 MB read of the intermediate tensor and one staging + one store phase.
+template <int MT, int KC, int PS>
+__device__ __forceinline__ void conv_taps(const unsigned char *lds, unsigned zoff, const __bf16 *wbase, int lr, int lg,
+                                          f32x4 (&acc)[MT][9], bf16x8 (&A)[2][MT])
+{
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        unsigned boff[9];
+#pragma unroll
+        for (int nt = 0; nt < 9; ++nt) {
+            const int pixel = nt * 16 + lr, y0 = pixel / 12;
+            int sy = y0 + dy, sx = pixel - 12 * y0 + dx;
+            bool inb = (unsigned)sy < 12u && (unsigned)sx < 12u;
+            boff[nt] = (inb ? (unsigned)((sy * 12 + sx) * PS) : zoff) + (unsigned)(lg * 16);
+        }
+#pragma unroll 1
+        for (int kc2 = 0; kc2 < KC; kc2 += 2) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int kc = kc2 + half;
+                {
+                    int nkc = kc + 1, ntap = tap;
+                    if (nkc == KC) { nkc = 0; ntap = tap + 1; }
+                    if (ntap < 9) {
+                        const __bf16 *wp = wbase + (size_t)(ntap * KC + nkc) * (16 * 512);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            A[half ^ 1][mt] = *reinterpret_cast<const bf16x8 *>(wp + (size_t)mt * 512);
+                    }
+                }
+                bf16x8 Bf[9];
+#pragma unroll
+                for (int nt = 0; nt < HIVE_CONV_BDEPTH; ++nt)
+                    Bf[nt] = *reinterpret_cast<const bf16x8 *>(lds + boff[nt] + kc * 64);
+#pragma unroll
+                for (int nt = 0; nt < 9; ++nt) {
+                    if (nt + HIVE_CONV_BDEPTH < 9)
+                        Bf[nt + HIVE_CONV_BDEPTH] =
+                            *reinterpret_cast<const bf16x8 *>(lds + boff[nt + HIVE_CONV_BDEPTH] + kc * 64);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[half][mt], Bf[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)
+resblock_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ W1, const float *__restrict__ b1,
+                const __bf16 *__restrict__ W2, const float *__restrict__ b2, __bf16 *__restrict__ Y)
+{
+    constexpr int CINP = 256, KC = 8, MT = 4, NT = 256;
+    constexpr int PS = CINP * 2 + HIVE_CONV_PAD;
+    constexpr unsigned ZOFF = 144 * PS;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[145 * PS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const long long b = blockIdx.x;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(X + b * 144 * 256);
+        for (int i = tid; i < 144 * 32; i += NT) *reinterpret_cast<uint4 *>(lds + (i >> 5) * PS + (i & 31) * 16) = src[i];
+        for (int i = tid; i < PS / 16; i += NT) *reinterpret_cast<uint4 *>(lds + ZOFF + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    f32x4 acc[MT][9];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 9; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const size_t woff = ((size_t)(wave * MT) * 64 + lane) * 8;
+    bf16x8 A[2][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) A[0][mt] = *reinterpret_cast<const bf16x8 *>(W1 + woff + (size_t)mt * 512);
+    __syncthreads();
+    conv_taps<MT, KC, PS>(lds, ZOFF, W1 + woff, lr, lg, acc, A);
+
+    // conv1 epilogue: relu(acc + b1) -> bf16, written over the board in LDS
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) A[0][mt] = *reinterpret_cast<const bf16x8 *>(W2 + woff + (size_t)mt * 512);
+    __syncthreads();                      // every wave has finished reading x from LDS
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int ch0 = (wave * MT + mt) * 16 + lg * 4;
+        const float4 bv = *reinterpret_cast<const float4 *>(b1 + ch0);
+#pragma unroll
+        for (int nt = 0; nt < 9; ++nt) {
+            const int pixel = nt * 16 + lr;
+            bf16x4 out = {(__bf16)fmaxf(acc[mt][nt][0] + bv.x, 0.f), (__bf16)fmaxf(acc[mt][nt][1] + bv.y, 0.f),
+                          (__bf16)fmaxf(acc[mt][nt][2] + bv.z, 0.f), (__bf16)fmaxf(acc[mt][nt][3] + bv.w, 0.f)};
+            *reinterpret_cast<bf16x4 *>(lds + pixel * PS + ch0 * 2) = out;
+            acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();                      // the intermediate board is complete
+    conv_taps<MT, KC, PS>(lds, ZOFF, W2 + woff, lr, lg, acc, A);
+
+    // conv2 epilogue: + b2 + x (skip), relu, one rounding, channels-last store
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int ch0 = (wave * MT + mt) * 16 + lg * 4;
+        const float4 bv = *reinterpret_cast<const float4 *>(b2 + ch0);
+#pragma unroll
+        for (int nt = 0; nt < 9; ++nt) {
+            const int pixel = nt * 16 + lr;
+            const size_t o = ((size_t)b * 144 + pixel) * 256 + ch0;
+            bf16x4 r = *reinterpret_cast<const bf16x4 *>(X + o);
+            bf16x4 out = {(__bf16)fmaxf(acc[mt][nt][0] + bv.x + (float)r[0], 0.f),
+                          (__bf16)fmaxf(acc[mt][nt][1] + bv.y + (float)r[1], 0.f),
+                          (__bf16)fmaxf(acc[mt][nt][2] + bv.z + (float)r[2], 0.f),
+                          (__bf16)fmaxf(acc[mt][nt][3] + bv.w + (float)r[3], 0.f)};
+            *reinterpret_cast<bf16x4 *>(Y + o) = out;
+        }
+    }
+}
+
 }  // namespace hive
 
 using namespace hive;
@@ -186,5 +308,17 @@ extern "C" int hive_nn_conv3x3(const void *x, int cin, const void *w, const floa
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(HIVE_E_DEVICE, std::string("hive_nn_conv3x3: ") + hipGetErrorString(e));
+    return HIVE_OK;
+}
+
+extern "C" int hive_nn_resblock(const void *x, const void *w1, const float *b1, const void *w2, const float *b2, void *y,
+                                int batch, void *stream)
+{
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y || batch <= 0 || x == y)
+        return set_error(HIVE_E_ARG, "hive_nn_resblock: bad argument (y must not alias x)");
+    hipLaunchKernelGGL(resblock_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)x,
+                       (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (__bf16 *)y);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(HIVE_E_DEVICE, std::string("hive_nn_resblock: ") + hipGetErrorString(e));
     return HIVE_OK;
 }

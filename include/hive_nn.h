@@ -27,6 +27,12 @@ extern "C" {
 int hive_nn_conv3x3(const void *x, int cin, const void *w, const float *bias, const void *residual, void *y,
                     int batch, int relu, void *stream);
 
+/* One residual block (alpha_net.py:36-54) in one launch: y = relu(conv2(relu(conv1(x) + b1)) + b2 + x), all
+ * tensors bf16 [batch][144][256], weights fragment-major as above, y must not alias x.  The intermediate
+ * activation stays in LDS. */
+int hive_nn_resblock(const void *x, const void *w1, const float *b1, const void *w2, const float *b2, void *y,
+                     int batch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,3 +186,29 @@ def test_trainer_bf16_autocast_close_to_fp32():
     for _ in range(3):
         l1 = bf16.step(x, pol, val)
     assert l1 < l0
+
+
+@pytest.mark.gpu
+def test_hip_resblock_matches_two_convs():
+    """hive_nn_resblock (both convolutions of a residual block in one launch, intermediate in LDS) against the two
+    hive_nn_conv3x3 launches it replaces: identical arithmetic, so bit-identical bf16 outputs."""
+    assert torch.cuda.is_available()
+    import ctypes
+    import hive_alphazero_amd as h
+    from hive_alphazero_amd.alpha_net import _frag_major
+    L = h.load()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    B = 7
+    x = torch.randn((B, 12, 12, 256), device="cuda", generator=g).to(torch.bfloat16)
+    w1 = _frag_major(torch.randn((256, 256, 3, 3), device="cuda", generator=g) * 0.03, x.device)
+    w2 = _frag_major(torch.randn((256, 256, 3, 3), device="cuda", generator=g) * 0.03, x.device)
+    b1 = torch.randn((256,), device="cuda", generator=g)
+    b2 = torch.randn((256,), device="cuda", generator=g)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    o = torch.empty_like(x); y_ref = torch.empty_like(x); y = torch.full_like(x, float("nan"))
+    assert L.hive_nn_conv3x3(P(x), 256, P(w1), P(b1), None, P(o), B, 1, None) == 0
+    assert L.hive_nn_conv3x3(P(o), 256, P(w2), P(b2), P(x), P(y_ref), B, 1, None) == 0
+    assert L.hive_nn_resblock(P(x), P(w1), P(b1), P(w2), P(b2), P(y), B, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    assert L.hive_nn_resblock(P(x), P(w1), P(b1), P(w2), P(b2), P(x), B, None) == -1     # in-place is refused
