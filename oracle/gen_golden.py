@@ -325,6 +325,65 @@ def cmd_selfplay(a):
     print("selfplay.json.gz rows", len(rows), "value_white", value_white)
 
 
+def recorded_game(gm, drop=None, bots=()):
+    """A golden random game as woker/sl.py's recorded-game steps; `drop` removes one ply so that the next
+    step is out of turn (exercises skip_turn), `bots` marks plies played by a bot."""
+    from hive_engine.config import index_char, index_number
+    codes = ["Q", "B1", "B2", "S1", "S2", "G1", "G2", "G3", "A1", "A2", "A3"]
+    steps = []
+    for i, rec in enumerate(gm["plies"]):
+        a = rec["a"]
+        if a is None or a < 0 or i == drop:
+            continue
+        cell, slot = divmod(a, 11)
+        steps.append([codes[slot], index_char[cell // 12], index_number[cell % 12], "W" if rec["t"] % 2 == 1 else "B",
+                      1 if i in bots else 0])
+    return steps
+
+
+def cmd_sl(a):
+    """woker/sl.py::get_buffer on recorded games derived from golden games (one complete, one with a dropped ply)."""
+    import contextlib
+    import io
+    import zlib
+    import woker.sl as sl
+    with gzip.open(os.path.join(GOLD, "games_full.json.gz"), "rt") as f:
+        games = json.load(f)["games"]
+    won = next(g for g in games if g["plies"][-1]["over"] and g["plies"][-1]["win"] != 0)
+    cases = []
+    def with_double_move(seed, at, total):
+        """Random recorded game in which the player to move at ply `at` is skipped (their opponent moves twice)."""
+        from hive_engine.config import index_char, index_number
+        codes = ["Q", "B1", "B2", "S1", "S2", "G1", "G2", "G3", "A1", "A2", "A3"]
+        rng = np.random.default_rng(seed)
+        g = _new_game()
+        steps = []
+        for ply in range(total):
+            if ply == at:
+                g.skip_turn()
+            acts = g.actions()
+            if not acts:
+                break
+            act = int(acts[rng.integers(len(acts))])
+            cell, slot = divmod(act, 11)
+            steps.append([codes[slot], index_char[cell // 12], index_number[cell % 12], "W" if g.player() == 0 else "B", 0])
+            g.move(act)
+        return steps
+
+    for steps in (recorded_game(won, None, (3, 8)), with_double_move(5, 13, 26), recorded_game(games[2], None, (0,))[:12]):
+        with contextlib.redirect_stdout(io.StringIO()):
+            data, _ = sl.get_buffer(steps)
+        rows = []
+        for state, policy, value, lens in data:
+            arr = np.asarray(state, dtype=np.float32)
+            rows.append({"crc": int(zlib.crc32(arr.tobytes())), "pol": [[i, float(x)] for i, x in enumerate(policy) if x != 0],
+                         "v": value, "lens": lens})
+        cases.append({"steps": steps, "rows": rows})
+        print("sl case: steps", len(steps), "rows", len(rows), "value0", rows[0]["v"] if rows else None, flush=True)
+    with gzip.open(os.path.join(GOLD, "sl.json.gz"), "wt", compresslevel=9) as f:
+        json.dump({"cases": cases}, f, separators=(",", ":"))
+
+
 def cmd_net(a):
     """alpha_zero/alpha_net.py::ChessNet: (1) same-seed init of the build's ChessNet gives identical
     tensors, (2) outputs of the reference net on planes of golden positions (CPU fp32)."""
@@ -386,6 +445,7 @@ if __name__ == "__main__":
     ps = sub.add_parser("selfplay")
     ps.add_argument("--sims", type=int, default=5)
     ps.add_argument("--seed", type=int, default=4)
+    sub.add_parser("sl")
     a = ap.parse_args()
     {"tables": cmd_tables, "games": cmd_games, "mcts": cmd_mcts, "net": cmd_net, "uct": cmd_uct,
-     "selfplay": cmd_selfplay}[a.cmd](a)
+     "selfplay": cmd_selfplay, "sl": cmd_sl}[a.cmd](a)

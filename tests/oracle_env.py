@@ -59,6 +59,32 @@ class OracleGamePlay:
     def decode_action(self, a):
         return divmod(int(a), 11)
 
+    def skip_turn(self):                 # env_hive.py:493-496 (state_key is not updated there)
+        self._g.skip_turn()
+
+    class _Tile:
+        def __init__(self, x, y):
+            self.index_xy = [x, y]
+
+    board_matrix = np.array([[None] * 12 for _ in range(12)], dtype=object)
+
+    def encode_action(self, action_list):
+        from hive_alphazero_amd.config import SLOT_KEYS
+        ids = set()
+        for piece, tiles in action_list.items():
+            for t in tiles:
+                ids.add((t.index_xy[0] * 12 + t.index_xy[1]) * 11 + SLOT_KEYS.index(piece))
+        return sorted(ids)
+
+
+for _x in range(12):
+    for _y in range(12):
+        OracleGamePlay.board_matrix[_x, _y] = OracleGamePlay._Tile(_x, _y)
+
+
+class _Unused:
+    pass
+
     def __deepcopy__(self, memo):
         c = OracleGamePlay.__new__(OracleGamePlay)
         c._g = self._g.copy()

@@ -180,3 +180,20 @@ def test_sharding_world_size_2_gloo(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["total"] == res["want"] and res["units"] == res["n"] and res["slowest"] == 2.0
+
+
+def test_sl_get_buffer_matches_reference():
+    """woker/sl.py::get_buffer mirror on recorded games (a finished game with bot-weighted moves, a game with
+    an out-of-turn step that triggers skip_turn, an unfinished prefix) -- CPU env path."""
+    from hive_alphazero_amd.sl import decode_piece, get_buffer
+    from oracle_env import OracleGamePlay
+    assert decode_piece("Q") == "<class 'pieces.Queen'>0" and decode_piece("G3") == "<class 'pieces.Grasshopper'>2"
+    with gzip.open(os.path.join(GOLD, "sl.json.gz"), "rt") as f:
+        gold = json.load(f)
+    for case in gold["cases"]:
+        data, _ = get_buffer(case["steps"], make_env=OracleGamePlay)
+        assert len(data) == len(case["rows"]) > 0
+        for (state, policy, value, lens), row in zip(data, case["rows"]):
+            assert int(zlib.crc32(np.asarray(state, dtype=np.float32).tobytes())) == row["crc"]
+            assert [[i, float(x)] for i, x in enumerate(policy) if x != 0] == row["pol"]
+            assert value == row["v"] and lens == row["lens"]

@@ -99,3 +99,21 @@ def test_gameplay_facade_matches_golden_game(golden_games):
             g.move(rec["a"])
     key, core = g.decode_action(858)
     assert key == "<class 'pieces.Queen'>0" and core == ("N", "13")
+
+
+@pytest.mark.gpu
+def test_sl_get_buffer_gpu_env():
+    """The SL ingest (woker/sl.py::get_buffer mirror) over the HIP-backed GamePlay: skip_turn, encode_action,
+    encode_board(player) and move(with_skip=False) against the reference's rows."""
+    import zlib
+    import torch
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.sl import get_buffer
+    with gzip.open(os.path.join(os.path.dirname(GOLD), "sl.json.gz"), "rt") as f:
+        gold = json.load(f)
+    for case in gold["cases"][:2]:
+        data, _ = get_buffer(case["steps"])
+        assert len(data) == len(case["rows"])
+        for (state, policy, value, lens), row in zip(data, case["rows"]):
+            assert int(zlib.crc32(np.asarray(state, dtype=np.float32).tobytes())) == row["crc"]
+            assert value == row["v"] and lens == row["lens"]
