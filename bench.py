@@ -57,7 +57,7 @@ def selfplay_measure(args, local_rank, world):
     from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
     torch.manual_seed(0)
     net = InferenceNet(ChessNet().cuda().eval(), dtype=torch.bfloat16)
-    sp = mcts.SelfPlay(args.games, args.sims, net, device=local_rank, seed=1234 + local_rank)
+    sp = mcts.SelfPlay(args.games, args.sims, net, device=local_rank, slots=args.slots, seed=1234 + local_rank)
     sp.stagger(seed=77 + local_rank)
     for _ in range(args.selfplay_warmup):
         sp.play_ply()
@@ -74,7 +74,7 @@ def selfplay_measure(args, local_rank, world):
     mean_len = (sum(sp.finished_lengths) / len(sp.finished_lengths) - 1.0) if sp.finished_lengths else 54.0
     leafs = args.games * args.sims * args.selfplay_plies
     out = {
-        "workload": f"selfplay_{args.games}x{args.sims}sims",
+        "workload": f"selfplay_{args.games}x{args.sims}sims" + (f"_slots{args.slots}" if args.slots > 1 else ""),
         "games_per_min": round(args.games * args.selfplay_plies / mean_len / el * 60.0, 2),
         "finished_games_in_window": finished, "window_plies": args.selfplay_plies, "window_s": round(el, 3),
         "mean_plies_per_finished_game": round(mean_len, 2), "ms_per_ply": round(el / args.selfplay_plies * 1e3, 2),
@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--sat-boards", type=int, default=1 << 20, help="batch size of the saturated side measurement")
     ap.add_argument("--games", type=int, default=1024, help="concurrent self-play games per GPU (BASELINE configs[2])")
     ap.add_argument("--sims", type=int, default=50)
+    ap.add_argument("--slots", type=int, default=1, help="leaves in flight per tree (virtual loss); BASELINE configs[4] uses 250 sims")
     ap.add_argument("--selfplay-plies", type=int, default=6, help="timed plies of the self-play side measurement (0 = skip)")
     ap.add_argument("--selfplay-warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline-selfplay", dest="cpu_baseline_selfplay", action="store_false")
