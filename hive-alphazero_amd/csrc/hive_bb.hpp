@@ -37,7 +37,7 @@ constexpr int kQuadPrev = 2 | (0 << 2) | (1 << 4) | (3 << 6);   // lanes 0,1,2 r
 constexpr int kQuadNext = 1 | (2 << 2) | (0 << 4) | (3 << 6);   // lanes 0,1,2 read 1,2,0 (cyclic next)
 constexpr int kQuadSwap1 = 1 | (0 << 2) | (3 << 4) | (2 << 6);
 constexpr int kQuadSwap2 = 2 | (3 << 2) | (0 << 4) | (1 << 6);
-constexpr int kQuadB0 = 0, kQuadB1 = 0x55, kQuadB2 = 0xAA;      // broadcast lane 0 / 1 / 2
+constexpr int kQuadB0 = 0, kQuadB1 = 0x55;                     // broadcast lane 0 / 1
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t quad(uint32_t v)
@@ -60,7 +60,6 @@ __device__ __forceinline__ BB bb_full()
     return BB{m, m};
 }
 __device__ __forceinline__ BB bb_not(BB a) { return bb_andn(bb_full(), a); }
-__device__ __forceinline__ BB bb_select(bool c, BB a, BB b) { return BB{c ? a.lo : b.lo, c ? a.hi : b.hi}; }
 
 // OR over the quad, result in every lane
 __device__ __forceinline__ uint32_t quad_or(uint32_t t)
