@@ -43,6 +43,12 @@ __device__ unsigned long long d_stamps[11][8];
 #endif
 
 constexpr int NW = 11;                 // waves per workgroup = piece slots per colour
+#ifndef HIVE_HIVE_STEPS
+#define HIVE_HIVE_STEPS 2              // flood expansions per convergence test: one-hive flood
+#endif
+#ifndef HIVE_ANT_STEPS
+#define HIVE_ANT_STEPS 2               // ... Ant reach flood
+#endif
 #ifndef HIVE_PIECE_WPE
 #define HIVE_PIECE_WPE 7                // waves per SIMD asked of the register allocator (72 VGPRs; measured best)
 #endif
@@ -147,8 +153,9 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     // two expansions per convergence test (the reductions and the loop branch cost as much as a step)
 #define HIVE_FLOOD_STEP()                                                                 \
     if (act) {                                                                            \
-        BB n1 = bb_or(reach, bb_and(bb_neighbours(reach), occp));                         \
-        BB nx = bb_or(n1, bb_and(bb_neighbours(n1), occp));                               \
+        BB nx = reach;                                                                    \
+        HIVE_UNROLL for (int u_ = 0; u_ < HIVE_HIVE_STEPS; ++u_)                          \
+            nx = bb_or(nx, bb_and(bb_neighbours(nx), occp));                              \
         bool covered = !bb_any(bb_andn(target, nx));                                      \
         bool fixed = bb_eq(nx, reach);                                                    \
         reach = nx;                                                                       \
@@ -191,8 +198,8 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 HIVE_COUNT_ITER();
                 HIVE_FLOOD_STEP()
                 if (aa) {
-                    BB n1 = bb_or(R, slide_step(ctx, R));
-                    BB nx = bb_or(n1, slide_step(ctx, n1));
+                    BB nx = R;
+                    HIVE_UNROLL for (int u = 0; u < HIVE_ANT_STEPS; ++u) nx = bb_or(nx, slide_step(ctx, nx));
                     if (bb_eq(nx, R)) aa = false;
                     R = nx;
                 }
