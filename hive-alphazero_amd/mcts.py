@@ -136,8 +136,9 @@ class SelfPlay:
         self._next_id = games
         # per running game: list of (packed features uint64[144], history words uint32[4,2,6] + length, turn,
         # visit policy float32[1584], mover) -- turned into the reference's rows when the game ends
-        self._open = {int(i): [] for i in range(games)}
-        self.finished_games = []     # list of (value_white, rows) ; rows as records.game_entries returns them
+        self._log = []               # per ply: host arrays of every game (features, history, records, policy, moved?)
+        self._start_ply = [0] * games   # index into the ply counter at which the game in each slot started
+        self.finished_games = []     # list of (value_white, plies) for the first max_finished_kept finished games
         self.max_finished_kept = 64
 
     def stagger(self, seed=0):
@@ -179,13 +180,26 @@ class SelfPlay:
         """self_play.py:165-191: value_white = +1 / -1 / 0; a draw or the length cap scores -1 for both."""
         from . import records
         for s in slots:
-            plies = self._open[s]
-            self._open[s] = []
-            if not plies:
+            start, self._start_ply[s] = self._start_ply[s], self.plies
+            if len(self.finished_games) >= self.max_finished_kept:
                 continue
-            vw = 1 if winner[s] == 1 else (-1 if winner[s] == 2 else 0)
-            if len(self.finished_games) < self.max_finished_kept:
+            plies = [self.ply_record(e, s) for e in self._log if e["ply"] >= start and e["moved"][s]]
+            if plies:
+                vw = 1 if winner[s] == 1 else (-1 if winner[s] == 2 else 0)
                 self.finished_games.append((vw, plies))
+
+    @staticmethod
+    def ply_record(entry, g):
+        """(packed features uint64[144], history words uint32[4,2,6], valid entries, turn, policy, mover) of game
+        slot g at one logged ply."""
+        turn = int(entry["boards"][g, 33])
+        persp = 0 if turn % 2 == 1 else 1
+        hl = int(entry["boards"][g, 35])
+        hlen = (hl & 15) if persp == 0 else (hl >> 4)
+        return (entry["feat"][g].copy(), entry["hist"][g, persp].copy(), hlen, turn, entry["policy"][g].copy(), persp)
+
+    def last_ply_record(self, g):
+        return self.ply_record(self._log[-1], g) if self._log and self._log[-1]["moved"][g] else None
 
     def finished_game_rows(self, k):
         """The k-th kept finished game as the reference's JSON rows [state, policy, value, [game_len, counter]]."""
@@ -207,20 +221,18 @@ class SelfPlay:
             self.records.append((self.search.root_planes.view(self.games, 144), policy.clone(), mover, self.game_id.clone()))
             if len(self.records) > 8:
                 self.records.pop(0)
-            # host copies for the per-game record (8 MB per ply at 1024 games)
-            feat_h = self.search.root_planes.view(self.games, 144).cpu().numpy().view("uint64")
-            pol_h = policy.cpu().numpy()
-            st_h = boards.cpu().numpy()
-            hist_h = hist.cpu().numpy().view("uint32").reshape(self.games, 2, 4, 2, 6)
-            act_h = action.cpu().numpy()
-            for g in range(self.games):
-                if act_h[g] == -2:
-                    continue
-                turn = int(st_h[g, 33])
-                persp = 0 if turn % 2 == 1 else 1
-                hl = int(st_h[g, 35])
-                hlen = (hl & 15) if persp == 0 else (hl >> 4)
-                self._open[g].append((feat_h[g].copy(), hist_h[g, persp].copy(), hlen, turn, pol_h[g].copy(), persp))
+            # host copies of this ply for the per-game records (8 MB per ply at 1024 games; whole arrays, the
+            # per-game rows are cut out only when a game ends)
+            self._log.append({
+                "ply": self.plies,
+                "feat": self.search.root_planes.view(self.games, 144).cpu().numpy().view("uint64"),
+                "policy": policy.cpu().numpy(),
+                "boards": boards.cpu().numpy(),
+                "hist": hist.cpu().numpy().view("uint32").reshape(self.games, 2, 4, 2, 6),
+                "moved": (action != -2).cpu().numpy(),
+            })
+            if len(self._log) > MAX_GAME_LENGTH + 1:
+                self._log.pop(0)
         # the env re-derives the legal masks and refuses anything not in them: the search's edges come
         # from the same kernels, so illegal_count() must stay 0 (asserted by the tests)
         self.env.step(action, sync=False)

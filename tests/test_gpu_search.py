@@ -203,8 +203,9 @@ def test_selfplay_records_match_env_planes(tmp_path):
         alive = (over.cpu().numpy() == 0) & (turn < 55)
         sp.play_ply()
         for g in range(48):
-            if alive[g] and sp._open[g]:
-                words, hw, hlen, t, pol, mover = sp._open[g][-1]
+            rec = sp.last_ply_record(g) if alive[g] else None
+            if rec is not None:
+                words, hw, hlen, t, pol, mover = rec
                 got = records.unpack_features(words, t, records.history_planes(hw, hlen))
                 assert np.array_equal(got, want[g].astype(np.float64)), g
                 assert abs(pol.sum() - 1.0) < 1e-4
