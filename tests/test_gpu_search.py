@@ -221,3 +221,31 @@ def test_selfplay_records_match_env_planes(tmp_path):
     back = records.load_data(path)
     assert len(back) == len(rows)
     sp.close()
+
+
+def test_selfplay_to_training_loop_closes():
+    """GPU self-play rows -> the reference's dataset layout (train.py:10-33: object array of [s, p, v]) ->
+    alpha_net.train / Trainer: the loop the reference runs between self_play.py and train.py."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd import mcts
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet, Trainer, train
+    torch.manual_seed(0)
+    net = ChessNet().cuda()
+    sp = mcts.SelfPlay(64, 4, InferenceNet(net.eval()), seed=21)
+    sp.stagger(seed=22)
+    for _ in range(12):
+        sp.play_ply()
+    sp._retire_finished()
+    assert sp.finished_games
+    rows = [r for k in range(min(3, len(sp.finished_games))) for r in sp.finished_game_rows(k)]
+    dataset = np.empty((len(rows), 3), dtype=object)
+    for i, (state, policy, value, _) in enumerate(rows):
+        dataset[i, 0], dataset[i, 1], dataset[i, 2] = np.array(state, dtype=np.float32), np.array(policy, dtype=np.float32), float(value)
+    losses = train(net, dataset[:16], epoch_start=0, epoch_stop=2, cpu=0, batch_size=8, log=lambda *_: None)
+    assert len(losses) == 2 and all(np.isfinite(l) for l in losses)
+    tr = Trainer(net)
+    x = torch.from_numpy(np.stack([d.transpose(2, 0, 1) for d in dataset[:8, 0]]))
+    pol = torch.from_numpy(np.stack(list(dataset[:8, 1])))
+    val = torch.tensor([float(v) for v in dataset[:8, 2]])
+    assert np.isfinite(tr.step(x, pol, val))
+    sp.close()
