@@ -246,6 +246,8 @@ def test_random_playout_vs_oracle_lockstep(hv):
                 done[i] = True
                 continue
             a = int(want[rng.integers(len(want))]) if want else -1
+            if ply > 2 and rng.random() < 0.04:
+                a = -1          # a forced pass / skip_turn (env_hive.py:100-103,493-496): history must not advance
             acts[i] = a
             g.move(a)
         if done.all():
