@@ -100,7 +100,9 @@ def choose(g, rng, policy):
     acts = g.actions()
     if not acts:
         return -1
-    if policy == "uniform" or rng.random() < 0.35:
+    if policy == "passy" and g.state.turn > 2 and rng.random() < 0.06:
+        return -1            # a voluntary pass: move(-1) is what skip-like callers do (env_hive.py:100-103)
+    if policy in ("uniform", "passy") or rng.random() < 0.35:
         return int(acts[rng.integers(len(acts))])
     occ = {}
     for pset in (g.white_pieces_set, g.black_pieces_set):
@@ -190,9 +192,9 @@ def cmd_tables(_):
 def cmd_games(a):
     import multiprocessing as mp
     jobs = []
-    pols = ["uniform", "beetle", "attack"]
+    pols = ["passy"] if a.passy else ["uniform", "beetle", "attack"]
     for i in range(a.games):
-        jobs.append((a.seed0 + i, pols[i % 3], not a.no_planes))
+        jobs.append((a.seed0 + i, pols[i % len(pols)], not a.no_planes))
     with mp.Pool(a.procs) as pool:
         games = []
         for k, gm in enumerate(pool.imap_unordered(play_game, jobs)):
@@ -436,6 +438,7 @@ if __name__ == "__main__":
     pg.add_argument("--seed0", type=int, default=0)
     pg.add_argument("--no-planes", action="store_true")
     pg.add_argument("--out", default=None)
+    pg.add_argument("--passy", action="store_true", help="games with voluntary passes")
     pm = sub.add_parser("mcts")
     pm.add_argument("--sims", type=int, default=50)
     pn = sub.add_parser("net")

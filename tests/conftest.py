@@ -23,5 +23,9 @@ def golden_tables():
 
 @pytest.fixture(scope="session")
 def golden_games():
-    with gzip.open(os.path.join(GOLD, "games_full.json.gz"), "rt") as f:
-        return json.load(f)["games"]
+    """60 reference games (uniform / beetle-happy / queen-attacking playouts) + 14 with voluntary passes."""
+    games = []
+    for name in ("games_full.json.gz", "games_pass.json.gz"):
+        with gzip.open(os.path.join(GOLD, name), "rt") as f:
+            games += json.load(f)["games"]
+    return games
