@@ -249,7 +249,10 @@ def main():
 
     selfplay = None
     if args.selfplay_plies > 0:
-        selfplay = selfplay_measure(args, local_rank, world)
+        try:
+            selfplay = selfplay_measure(args, local_rank, world)
+        except Exception as exc:                 # the headline line must still come out
+            selfplay = {"error": repr(exc), "games_per_min": 0.0, "leaf_evals_per_s": 0.0}
         if world > 1:
             t = torch.tensor([selfplay["games_per_min"], selfplay["leaf_evals_per_s"]], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
