@@ -109,6 +109,7 @@ struct PieceInfo {
 // `type` and the loops' trip tests are wave-uniform.
 // own == true : get_actions semantics (env_hive.py:207-285)
 // own == false: mini_black_actions semantics for an enemy piece (env_hive.py:449-485)
+template <int ANT_STEPS>
 __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint32_t *occ_p, const uint32_t *topw_p,
                                                  const uint8_t *pinfo, int q, int type, bool own, bool valid)
 {
@@ -199,7 +200,7 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 HIVE_FLOOD_STEP()
                 if (aa) {
                     BB nx = R;
-                    HIVE_UNROLL for (int u = 0; u < HIVE_ANT_STEPS; ++u) nx = bb_or(nx, slide_step(ctx, nx));
+                    HIVE_UNROLL for (int u = 0; u < ANT_STEPS; ++u) nx = bb_or(nx, slide_step(ctx, nx));
                     if (bb_eq(nx, R)) aa = false;
                     R = nx;
                 }
@@ -327,7 +328,7 @@ __device__ __forceinline__ void scatter_dests(uint32_t *mrow, BB D, int slot)
 // GamePlay.make_state_value; history planes 36-43 and plane 31 are added by hive_expand_kernel).
 // There is no barrier after the piece work: each wave ORs its results into LDS and leaves; the
 // last wave to finish writes the workgroup's boards out.
-template <bool FULL>
+template <bool FULL, bool PRIO>
 __global__ void __launch_bounds__(NW * 64, HIVE_PIECE_WPE)
 hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restrict__ mask,
                   int32_t *__restrict__ count, unsigned long long *__restrict__ feat)
@@ -394,11 +395,19 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     const unsigned turn = state_byte(st, 33);
     const int stm = (turn & 1u) ? 0 : 1;
     const int type = slot_type(wv);
+    if (PRIO) {
+        // small batches (<= 1 workgroup per CU): the Ant and Spider waves are the critical path, let them win the
+        // issue arbitration against the light waves sharing their SIMD (-10 % at 4096 boards; above ~16 K boards
+        // starving the light waves costs throughput, so large launches use PRIO = false)
+        if (type == T_ANT) __builtin_amdgcn_s_setprio(3);
+        else if (type == T_SPIDER) __builtin_amdgcn_s_setprio(2);
+    }
     int q;
     bool own;
     if (!FULL) { q = stm * 11 + wv; own = true; }
     else { int col = item >> 3; q = col * 11 + wv; own = (col == stm); }
-    PieceInfo pc = piece_dests(st, sm.occ[bl], sm.topw[bl], sm.pinfo[bl], q, type, own, valid);
+    // latency-tuned launches also take three Ant expansions per convergence test (fewer loop trips)
+    PieceInfo pc = piece_dests<PRIO ? 3 : HIVE_ANT_STEPS>(st, sm.occ[bl], sm.topw[bl], sm.pinfo[bl], q, type, own, valid);
     HIVE_STAMP(1);
     if (own && (mask != nullptr || count != nullptr)) {
         scatter_dests(sm.mask[bl], pc.D, wv);
@@ -707,13 +716,19 @@ int hive_device_count(void)
     return c;
 }
 
+constexpr int kPrioMaxBoards = 16384;      // measured crossover of the s_setprio variant (tools/ablate.py)
+
 static int launch_pieces(const HiveBoard *boards, int n, uint32_t *mask, int32_t *count, int16_t *list,
                          hipStream_t stream)
 {
     if (n <= 0 || boards == nullptr) return fail(HIVE_E_ARG, "movegen: n <= 0 or boards == NULL");
     if (list != nullptr && mask == nullptr) return fail(HIVE_E_ARG, "movegen: the id list needs the mask buffer too");
-    hipLaunchKernelGGL((hive_piece_kernel<false>), dim3((unsigned)((n + 15) / 16)), dim3(NW * 64), 0, stream, boards, n,
-                       mask, count, (unsigned long long *)nullptr);
+    if (n <= kPrioMaxBoards)
+        hipLaunchKernelGGL((hive_piece_kernel<false, true>), dim3((unsigned)((n + 15) / 16)), dim3(NW * 64), 0, stream,
+                           boards, n, mask, count, (unsigned long long *)nullptr);
+    else
+        hipLaunchKernelGGL((hive_piece_kernel<false, false>), dim3((unsigned)((n + 15) / 16)), dim3(NW * 64), 0, stream,
+                           boards, n, mask, count, (unsigned long long *)nullptr);
     HIP_TRY(hipGetLastError());
     if (list != nullptr) {
         hipLaunchKernelGGL(hive_list_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream,
@@ -729,8 +744,12 @@ static int launch_encode(const HiveBoard *boards, const HiveHistory *hist, int n
     if (n <= 0 || boards == nullptr || planes == nullptr || feat == nullptr)
         return fail(HIVE_E_ARG, "encode: n <= 0 or a NULL buffer");
     if (dtype < 0 || dtype > 2 || layout < 0 || layout > 1) return fail(HIVE_E_ARG, "encode: unknown dtype/layout");
-    hipLaunchKernelGGL((hive_piece_kernel<true>), dim3((unsigned)((n + 7) / 8)), dim3(NW * 64), 0, stream, boards, n,
-                       mask, count, feat);
+    if (n <= kPrioMaxBoards / 2)
+        hipLaunchKernelGGL((hive_piece_kernel<true, true>), dim3((unsigned)((n + 7) / 8)), dim3(NW * 64), 0, stream, boards,
+                           n, mask, count, feat);
+    else
+        hipLaunchKernelGGL((hive_piece_kernel<true, false>), dim3((unsigned)((n + 7) / 8)), dim3(NW * 64), 0, stream, boards,
+                           n, mask, count, feat);
     HIP_TRY(hipGetLastError());
     const long long items = (long long)n * (kCells * HIVE_PLANES / 8);
     dim3 grid((unsigned)((items + 255) / 256));
