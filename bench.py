@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--selfplay-plies", type=int, default=6, help="timed plies of the self-play side measurement (0 = skip)")
     ap.add_argument("--selfplay-warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline-selfplay", dest="cpu_baseline_selfplay", action="store_false")
+    ap.add_argument("--no-overlap", action="store_true", help="skip the 4-stream overlapped side measurement (profiling runs: "
+                    "concurrent launches stretch the per-kernel durations rocprof reports)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
                     "the multi-rank path on a single GPU")
     args = ap.parse_args()
@@ -203,7 +205,7 @@ def main():
     # side measurement: the same 4096-board steps, independent batches issued round-robin on 4 HIP streams
     # (what a self-play engine with several game groups does); NOT the headline value
     overlapped = None
-    if rank == 0:
+    if rank == 0 and not args.no_overlap:
         streams = [torch.cuda.Stream() for _ in range(4)]
         outs = [(torch.empty_like(mask), torch.empty_like(count)) for _ in streams]
         torch.cuda.synchronize()
