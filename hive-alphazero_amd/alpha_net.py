@@ -239,8 +239,11 @@ class InferenceNet:
             rb = getattr(net, "res_%i" % i)
             self.blocks.append((prep(*_fold(rb.conv1, rb.bn1)), prep(*_fold(rb.conv2, rb.bn2))))
         ob = net.outblock
-        self.vconv = prep(*_fold(ob.conv, ob.bn))
-        self.pconv = prep(*_fold(ob.conv1, ob.bn1))
+        # the two 1x1 head convolutions are plain GEMMs over the NHWC activations ([B*144, 256] x [256, k])
+        wv, bv = _fold(ob.conv, ob.bn)
+        wp, bp = _fold(ob.conv1, ob.bn1)
+        self.vconv = (wv.reshape(1, 256).to(dev, dtype).contiguous(), bv.to(dev, dtype))
+        self.pconv = (wp.reshape(128, 256).to(dev, dtype).contiguous(), bp.to(dev, dtype))
         # the policy FC consumes the head in NHWC order: permute its columns once (c*144+hw -> hw*128+c)
         wfc = ob.fc.weight.detach().float().view(ACTIONS, 128, 144).permute(0, 2, 1).reshape(ACTIONS, 144 * 128)
         self.fc = (wfc.to(dev, dtype).contiguous(), ob.fc.bias.detach().to(dev, dtype))
@@ -294,11 +297,11 @@ class InferenceNet:
                 o = F.conv2d(o, w2, b2, padding=1)
                 s = F.relu(o + s)
         B = s.shape[0]
-        v = F.relu(F.conv2d(s, self.vconv[0], self.vconv[1])).float().reshape(B, 144)
+        flat = s.permute(0, 2, 3, 1).reshape(B * 144, 256)             # NHWC rows (a view: s is channels-last)
+        v = F.relu(F.linear(flat, *self.vconv)).float().reshape(B, 144)
         v = F.relu(F.linear(v, *self.fc1))
         v = torch.tanh(F.linear(v, *self.fc2)).reshape(B)
-        p = F.relu(F.conv2d(s, self.pconv[0], self.pconv[1]))          # [B,128,12,12] channels-last
-        p = p.permute(0, 2, 3, 1).reshape(B, 144 * 128)                # NHWC flatten (matches self.fc columns)
+        p = F.relu(F.linear(flat, *self.pconv)).reshape(B, 144 * 128)  # NHWC flatten (matches self.fc columns)
         p = F.linear(p, *self.fc).float()
         return torch.softmax(p, dim=1), v
 
