@@ -144,6 +144,7 @@ def main():
                     "the multi-rank path on a single GPU")
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -184,6 +185,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_setup = time.perf_counter() - t_start
     for _ in range(args.warmup):
         step()
     barrier()
@@ -202,6 +204,7 @@ def main():
     wall_max = float(tt.item())
     mean_legal = float(count.float().mean().item())
 
+    t_side0 = time.perf_counter()
     # side measurement: the same 4096-board steps, independent batches issued round-robin on 4 HIP streams
     # (what a self-play engine with several game groups does); NOT the headline value
     overlapped = None
@@ -261,6 +264,7 @@ def main():
             selfplay["games_per_min_all_gpus"] = round(float(t[0].item()), 2)
             selfplay["leaf_evals_per_s_all_gpus"] = round(float(t[1].item()), 1)
 
+    t_side = time.perf_counter() - t_side0
     if rank == 0:
         launch_us = dev_ms * 1e3 / args.steps
         achieved = n * ALGO_BYTES_PER_BOARD / (launch_us * 1e-6) / 1e9
@@ -288,8 +292,13 @@ def main():
             "saturated": sat,
             "selfplay": selfplay,
         }
+        t_cpu0 = time.perf_counter()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(boards.cpu().numpy())
+        # where the process's wall time goes (the timed region is only the K headline steps)
+        out["wall_s"] = {"imports_and_corpus": round(t_setup, 2), "timed_region": round(wall_max, 4),
+                         "side_measurements_incl_selfplay_and_its_cpu_baseline": round(t_side, 2),
+                         "movegen_cpu_baseline": round(time.perf_counter() - t_cpu0, 2)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
