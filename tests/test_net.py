@@ -212,3 +212,51 @@ def test_hip_resblock_matches_two_convs():
     torch.cuda.synchronize()
     assert torch.equal(y, y_ref)
     assert L.hive_nn_resblock(P(x), P(w1), P(b1), P(w2), P(b2), P(x), B, None) == -1     # in-place is refused
+
+
+_DDP_WORKER = r"""
+import sys, json
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from hive_alphazero_amd import dist as hd
+from hive_alphazero_amd.alpha_net import ChessNet, Trainer
+rank, local_rank, world = hd.init("gloo")
+torch.set_num_threads(3)
+torch.manual_seed(0)                      # same initial weights on every rank
+net = ChessNet()
+before = float(sum(p.double().abs().sum() for p in net.parameters()))
+tr = Trainer(net, lr=1e-3)                # picks DistributedDataParallel up from the process group
+assert tr.model is not tr.net
+g = torch.Generator().manual_seed(100 + rank)   # a different shard of rows per rank
+losses = []
+for _ in range(2):
+    x = (torch.rand(3, 56, 12, 12, generator=g) < 0.1).float()
+    pi = torch.softmax(torch.randn(3, 1584, generator=g), 1)
+    z = torch.sign(torch.randn(3, generator=g))
+    losses.append(tr.step(x, pi, z))
+after = float(sum(p.double().abs().sum() for p in net.parameters()))
+sums = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+dist.all_gather(sums, torch.tensor([after], dtype=torch.float64))
+if rank == 0:
+    print(json.dumps({"before": before, "after": [float(s) for s in sums], "losses": losses}))
+dist.destroy_process_group()
+"""
+
+
+def test_trainer_ddp_world_size_2_gloo(tmp_path):
+    """the one place a collective belongs.  Two ranks train on different rows; the gradient
+    all-reduce keeps their weights identical."""
+    import subprocess
+    import sys
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(_DDP_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29583")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29583", str(script), root],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["after"][0] == res["after"][1] != res["before"]
+    assert all(np.isfinite(l) for l in res["losses"])
