@@ -26,7 +26,19 @@ HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md "HB
 MOVEGEN_TRAFFIC_BYTES_PER_BOARD = 327
 
 
-def cpu_baseline(boards_np, budget_s=12.0):
+def host_cores(cap=16):
+    """Host threads worth starting: the affinity mask, cut down to the cgroup CPU quota (a one-GPU box grants 16)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(cores, cap))
+
+
+def cpu_baseline(boards_np, budget_s=12.0, all_cores_s=4.0):
     """The C oracle (kind "port") timed on ONE host core over a bounded sample of the same corpus."""
     import numpy as np
     from oracle import oracle_py as O
@@ -41,8 +53,27 @@ def cpu_baseline(boards_np, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s:
             break
-    return {"value": round(done / el / 1e6, 6), "unit": "Mboards/s", "cores": 1, "kind": "port",
-            "sample": f"{done} positions ({done // n} passes over the {n}-board corpus), oracle/hive_oracle.c, 1 thread"}
+    out = {"value": round(done / el / 1e6, 6), "unit": "Mboards/s", "cores": 1, "kind": "port",
+           "sample": f"{done} positions ({done // n} passes over the {n}-board corpus), oracle/hive_oracle.c, 1 thread"}
+    # the same oracle on every host core this process may use (ctypes releases the GIL): one corpus shard per thread
+    from concurrent.futures import ThreadPoolExecutor
+    cores = host_cores()
+    if cores > 1 and all_cores_s > 0:
+        bounds = [(n * i // cores, n * (i + 1) // cores) for i in range(cores)]
+        def shard(b):
+            lo, hi = b
+            O.batch_legal(st["turn"][lo:hi], st["pos"][lo:hi], st["lvl"][lo:hi], st["nmt_mode"][lo:hi], want_masks=False)
+        done2, t1 = 0, time.perf_counter()
+        with ThreadPoolExecutor(cores) as pool:
+            while True:
+                list(pool.map(shard, bounds))
+                done2 += n
+                el2 = time.perf_counter() - t1
+                if el2 >= all_cores_s:
+                    break
+        out["all_cores"] = {"value": round(done2 / el2 / 1e6, 6), "unit": "Mboards/s", "cores": cores,
+                            "sample": f"{done2} positions, {cores} threads, one corpus shard each"}
+    return out
 
 
 GFLOP_PER_LEAF = 6.560114816         # 3,280,057,408 MAC x 2 per board, SURVEY.md 8a a22
@@ -91,10 +122,11 @@ def selfplay_measure(args, local_rank, world):
     return out
 
 
-def selfplay_cpu_baseline(sims, plies=30):
+def selfplay_cpu_baseline(sims, budget_s=10.0):
     """The reference's process model on ONE host core: sequential HivePlayer (hive_alphazero_amd.solo_play, pinned
     bit-exact to woker/solo_play.py) over the CPU oracle env, with a stub evaluator -- i.e. env + tree only, the
-    network cost is EXCLUDED (the reference ran it on a separate GPU thread).  A bounded sample of `plies` moves."""
+    network cost is EXCLUDED (the reference ran it on a separate GPU thread).  Whole games from the opening position,
+    as many as fit in `budget_s` seconds."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import hive_alphazero_amd.solo_play as sp
@@ -102,26 +134,22 @@ def selfplay_cpu_baseline(sims, plies=30):
     from oracle_env import OracleGamePlay
     sp.SEARCH_THREADS = 1
     np.random.seed(0)
-    g = OracleGamePlay()
-    rng = np.random.default_rng(0)
-    for _ in range(8):
-        acts = g.actions()
-        g.move(int(acts[rng.integers(len(acts))]))
     player = sp.HivePlayer(pipes=[StubPipe()])
     player.simulation_num_per_move = sims
     t0 = time.perf_counter()
-    done = 0
-    for _ in range(plies):
-        if g.game_is_over() or g.state.turn >= 55:
-            break
-        a, _ = player.action(g)
-        g.move(a)
-        done += 1
+    plies = games = 0
+    while time.perf_counter() - t0 < budget_s:
+        g = OracleGamePlay()
+        while not (g.game_is_over() or g.state.turn >= 55) and time.perf_counter() - t0 < budget_s:
+            a, _ = player.action(g)
+            g.move(a)
+            plies += 1
+        games += 1
     el = time.perf_counter() - t0
-    plies = max(done, 1)
-    return {"value": round(60.0 / (el / plies * 54.0), 4), "unit": "games/min", "cores": 1, "kind": "port",
-            "sample": f"{plies} searched plies at {sims} sims from ply 8, sequential HivePlayer mirror + C oracle env, "
-                      "stub evaluator (network cost excluded), extrapolated to 54-ply games"}
+    return {"value": round(60.0 / (el / max(plies, 1) * 54.0), 4), "unit": "games/min", "cores": 1, "kind": "port",
+            "sample": f"{plies} searched plies ({games} games from the opening, the last one cut by the {budget_s:.0f} s budget) at "
+                      f"{sims} sims, sequential HivePlayer mirror + C oracle env, stub evaluator (network cost excluded), "
+                      "per 54-ply game"}
 
 
 def main():
@@ -252,6 +280,32 @@ def main():
                "frac_of_hbm_peak": round(nb * ALGO_BYTES_PER_BOARD / ms / 1e6 / HBM_PEAK_GBS, 5)}
         del big, bm, bc
 
+    # side measurement: the boundary handing over HOST buffers -- pinned boards in, pinned mask + count out, per step
+    pcie = None
+    if rank == 0 and not args.no_overlap:
+        hb = boards.cpu().pin_memory()
+        hm, hc = torch.empty(mask.shape, dtype=mask.dtype).pin_memory(), torch.empty(count.shape, dtype=count.dtype).pin_memory()
+        db = torch.empty_like(boards)
+        dbp = ctypes.c_void_p(db.data_ptr())
+        def hstep():
+            db.copy_(hb, non_blocking=True)
+            L.hive_movegen_launch(dbp, n, mp, cp, None, sp)
+            hm.copy_(mask, non_blocking=True)
+            hc.copy_(count, non_blocking=True)
+        for _ in range(20):
+            hstep()
+        torch.cuda.synchronize()
+        k = max(args.steps // 4, 1)
+        t1 = time.perf_counter()
+        for _ in range(k):
+            hstep()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        pcie = {"Mboards_per_s": round(n * k / el / 1e6, 2), "ms_per_step": round(el * 1e3 / k, 6),
+                "host_bytes_per_step": int(hb.numel() * hb.element_size() + hm.numel() * 4 + hc.numel() * 4),
+                "note": "pinned host buffers, one stream, copies and kernel serialised; never the headline value"}
+        assert torch.equal(hm, mask.cpu())
+
     selfplay = None
     if args.selfplay_plies > 0:
         try:
@@ -290,6 +344,7 @@ def main():
                          "note": "VALU-issue bound: 4096 boards = 256 workgroups x 11 waves, ~2.75 waves per SIMD; see saturated"},
             "overlapped_4_streams": overlapped,
             "saturated": sat,
+            "host_buffers_pcie_inclusive": pcie,
             "selfplay": selfplay,
         }
         t_cpu0 = time.perf_counter()

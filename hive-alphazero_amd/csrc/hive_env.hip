@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <new>
 #include <type_traits>
 #include <cstring>
 #include <string>
@@ -329,7 +330,7 @@ __device__ __forceinline__ void scatter_dests(uint32_t *mrow, BB D, int slot)
 // There is no barrier after the piece work: each wave ORs its results into LDS and leaves; the
 // last wave to finish writes the workgroup's boards out.
 template <bool FULL, bool PRIO>
-__global__ void __launch_bounds__(NW * 64, HIVE_PIECE_WPE)
+__global__ void __launch_bounds__(NW * 64, FULL ? 5 : HIVE_PIECE_WPE)
 hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restrict__ mask,
                   int32_t *__restrict__ count, unsigned long long *__restrict__ feat)
 {
@@ -804,26 +805,39 @@ int hive_leaf_launch(const HiveBoard *boards, const HiveHistory *hist, int n, vo
     return HIVE_OK;
 }
 
+static int batch_alloc(HiveBatch *h)
+{
+    const size_t n = (size_t)h->n;
+    HIP_TRY(hipMalloc(&h->boards, sizeof(HiveBoard) * n));
+    HIP_TRY(hipMalloc(&h->hist, sizeof(HiveHistory) * n));
+    HIP_TRY(hipMalloc(&h->legal, sizeof(uint32_t) * HIVE_MASK_WORDS * n));
+    HIP_TRY(hipMalloc(&h->legal_count, sizeof(int32_t) * n));
+    HIP_TRY(hipMalloc(&h->legal_list, sizeof(int16_t) * HIVE_LIST_CAP * n));
+    HIP_TRY(hipMalloc(&h->feat, sizeof(unsigned long long) * kCells * n));
+    HIP_TRY(hipMalloc(&h->illegal, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->illegal, 0, sizeof(unsigned long long)));
+    return hive_batch_reset(h, nullptr, h->n);
+}
+
 int hive_batch_create(int n, int device, HiveBatch **out)
 {
     if (n <= 0 || out == nullptr) return fail(HIVE_E_ARG, "hive_batch_create: n <= 0 or out == NULL");
+    *out = nullptr;
     int cnt = hive_device_count();
     if (cnt <= 0) return fail(HIVE_E_DEVICE, "hive_batch_create: no HIP device visible (this library has no CPU path)");
     if (device < 0 || device >= cnt) return fail(HIVE_E_ARG, "hive_batch_create: bad device ordinal");
     HIP_TRY(hipSetDevice(device));
-    HiveBatch *h = new HiveBatch();
+    HiveBatch *h = new (std::nothrow) HiveBatch();
+    if (h == nullptr) return fail(HIVE_E_DEVICE, "hive_batch_create: out of host memory");
     h->n = n;
     h->device = device;
-    HIP_TRY(hipMalloc(&h->boards, sizeof(HiveBoard) * (size_t)n));
-    HIP_TRY(hipMalloc(&h->hist, sizeof(HiveHistory) * (size_t)n));
-    HIP_TRY(hipMalloc(&h->legal, sizeof(uint32_t) * HIVE_MASK_WORDS * (size_t)n));
-    HIP_TRY(hipMalloc(&h->legal_count, sizeof(int32_t) * (size_t)n));
-    HIP_TRY(hipMalloc(&h->legal_list, sizeof(int16_t) * HIVE_LIST_CAP * (size_t)n));
-    HIP_TRY(hipMalloc(&h->feat, sizeof(unsigned long long) * kCells * (size_t)n));
-    HIP_TRY(hipMalloc(&h->illegal, sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(h->illegal, 0, sizeof(unsigned long long)));
+    int rc = batch_alloc(h);
+    if (rc != HIVE_OK) {            // a partly built handle never leaves the library
+        hive_batch_destroy(h);
+        return rc;
+    }
     *out = h;
-    return hive_batch_reset(h, nullptr, n);
+    return HIVE_OK;
 }
 
 int hive_batch_destroy(HiveBatch *h)

@@ -6,6 +6,7 @@
 // for the reference functions each entry point replaces.
 #include <hip/hip_runtime.h>
 
+#include <new>
 #include <string>
 
 #include "../../include/hive_search.h"
@@ -453,20 +454,9 @@ static hipError_t alloc(HiveSearch *s, T **p, size_t count)
 
 extern "C" {
 
-int hive_search_create(int games, int max_nodes, int slots, int device, uint64_t seed, HiveSearch **out)
+static int search_alloc(HiveSearch *s, int games, int max_nodes, int slots)
 {
-    if (games <= 0 || max_nodes < 2 || slots < 1 || slots > HIVE_MAX_SLOTS || !out)
-        return hive::set_error(HIVE_E_ARG, "hive_search_create: bad argument");
-    int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
-        return hive::set_error(HIVE_E_DEVICE, "hive_search_create: no HIP device visible (no CPU path)");
-    if (device < 0 || device >= cnt) return hive::set_error(HIVE_E_ARG, "hive_search_create: bad device ordinal");
-    S_TRY(hipSetDevice(device));
-    HiveSearch *s = new HiveSearch();
-    s->device = device;
     SearchDev &d = s->d;
-    d.G = games; d.MN = max_nodes; d.L = slots; d.seed = seed;
-    d.prm = HiveSearchParams{0.7f, 0.25f, 0.3f, 55};
     const size_t GN = (size_t)games * max_nodes, GE = GN * EC, LG = (size_t)slots * games;
     S_TRY(alloc(s, &d.node_board, GN));
     S_TRY(alloc(s, &d.node_hist, GN));
@@ -496,6 +486,31 @@ int hive_search_create(int games, int max_nodes, int slots, int device, uint64_t
     S_TRY(hipMemset(d.leaf_kind, 0, LG));
     S_TRY(hipMemset(d.path_len, 0, sizeof(int32_t) * LG));
     S_TRY(hipMemset(d.node_term, 0, GN));
+    return HIVE_OK;
+}
+
+int hive_search_destroy(HiveSearch *s);
+
+int hive_search_create(int games, int max_nodes, int slots, int device, uint64_t seed, HiveSearch **out)
+{
+    if (games <= 0 || max_nodes < 2 || slots < 1 || slots > HIVE_MAX_SLOTS || !out)
+        return hive::set_error(HIVE_E_ARG, "hive_search_create: bad argument");
+    *out = nullptr;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+        return hive::set_error(HIVE_E_DEVICE, "hive_search_create: no HIP device visible (no CPU path)");
+    if (device < 0 || device >= cnt) return hive::set_error(HIVE_E_ARG, "hive_search_create: bad device ordinal");
+    S_TRY(hipSetDevice(device));
+    HiveSearch *s = new (std::nothrow) HiveSearch();
+    if (s == nullptr) return hive::set_error(HIVE_E_DEVICE, "hive_search_create: out of host memory");
+    s->device = device;
+    s->d.G = games; s->d.MN = max_nodes; s->d.L = slots; s->d.seed = seed;
+    s->d.prm = HiveSearchParams{0.7f, 0.25f, 0.3f, 55};
+    int rc = search_alloc(s, games, max_nodes, slots);
+    if (rc != HIVE_OK) {            // free whatever was allocated; the caller never sees a partial handle
+        hive_search_destroy(s);
+        return rc;
+    }
     *out = s;
     return HIVE_OK;
 }
