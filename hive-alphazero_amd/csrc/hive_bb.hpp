@@ -42,7 +42,7 @@ constexpr int kQuadB0 = 0, kQuadB1 = 0x55;                     // broadcast lane
 template <int CTRL>
 __device__ __forceinline__ uint32_t quad(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);   // bound_ctrl: no "old" operand to set up
 }
 
 __device__ __forceinline__ int quad_lane() { return (int)(threadIdx.x & 3u); }

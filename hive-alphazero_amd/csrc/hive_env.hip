@@ -32,6 +32,7 @@ namespace hive {
 __device__ const Tables d_tables = kTables;
 #ifdef HIVE_DBG_ITERS
 __device__ unsigned long long d_iters[32];
+__device__ unsigned long long d_hist[5][32];     // trips-per-wave histogram by piece type
 __device__ unsigned long long d_stamps[11][8];
 #define HIVE_STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x % 16 == 0) atomicAdd(&d_stamps[wv][i], (unsigned long long)(clock64() - t_start)); } while (0)
 #else
@@ -246,7 +247,12 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     }
 #undef HIVE_FLOOD_STEP
 #ifdef HIVE_DBG_ITERS
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&d_iters[type], (unsigned long long)dbg_it); atomicAdd(&d_iters[8 + type], 1ull); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&d_iters[type], (unsigned long long)dbg_it);
+        atomicAdd(&d_iters[8 + type], 1ull);
+        atomicMax(&d_iters[16 + type], (unsigned long long)dbg_it);
+        if (dbg_it < 32) atomicAdd(&d_hist[type][dbg_it], 1ull);
+    }
 #endif
     const bool movable = on_top && !pinned;
 
@@ -974,7 +980,8 @@ int hive_batch_import(HiveBatch *h, const HiveBoard *boards, const HiveHistory *
 #ifdef HIVE_DBG_ITERS
 int hive_debug_iters(unsigned long long *host16)
 {
-    HIP_TRY(hipMemcpyFromSymbol(host16, HIP_SYMBOL(hive::d_iters), sizeof(unsigned long long) * 16));
+    HIP_TRY(hipMemcpyFromSymbol(host16, HIP_SYMBOL(hive::d_iters), sizeof(unsigned long long) * 32));
+    HIP_TRY(hipMemcpyFromSymbol(host16 + 32, HIP_SYMBOL(hive::d_hist), sizeof(unsigned long long) * 160));
     return HIVE_OK;
 }
 int hive_debug_stamps(unsigned long long *host88)

@@ -1,0 +1,22 @@
+"""Loop-trip statistics of the piece kernel (debug build with -DHIVE_DBG_ITERS): per piece type, the mean and maximum
+number of fused flood-loop trips a wave (16 boards) takes, and the histogram -- the launch time of a small batch is set
+by the slowest wave, not by the mean."""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hive_alphazero_amd import playout
+L = ctypes.CDLL(sys.argv[1])
+L.hive_movegen_launch.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
+n = 4096
+boards = playout.random_positions(n, seed=1000)
+mask = torch.empty((n, 50), dtype=torch.int32, device="cuda")
+cnt = torch.empty((n,), dtype=torch.int32, device="cuda")
+L.hive_movegen_launch(boards.data_ptr(), n, mask.data_ptr(), cnt.data_ptr(), None, None)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 192)()
+assert L.hive_debug_iters(buf) == 0
+v = np.array(buf[:], dtype=np.int64)
+names = ["queen", "beetle", "spider", "grasshopper", "ant"]
+for t, nm in enumerate(names):
+    hist = v[32 + 32 * t: 64 + 32 * t]
+    print(f"{nm:12s} waves {v[8 + t]:5d}  mean trips {v[t] / max(v[8 + t], 1):5.2f}  max {v[16 + t]:3d}  hist {list(hist[:int(v[16 + t]) + 1])}")
