@@ -52,9 +52,10 @@ constexpr int NW = 11;                 // waves per workgroup = piece slots per 
 #define HIVE_ANT_STEPS 2               // ... Ant reach flood
 #endif
 #ifndef HIVE_PIECE_WPE
-#define HIVE_PIECE_WPE 7                // waves per SIMD asked of the register allocator (72 VGPRs; measured best)
+#define HIVE_PIECE_WPE 6                // waves per SIMD asked of the register allocator (two 11-wave workgroups per CU)
 #endif
 constexpr unsigned kHand = 255u;
+constexpr int kPinWaves = 3;           // waves 0-2 run the one-hive test for all 176 (board, piece) items of a workgroup
 
 enum PieceType { T_QUEEN = 0, T_BEETLE = 1, T_SPIDER = 2, T_GRASS = 3, T_ANT = 4 };
 __device__ __forceinline__ int slot_type(int slot)
@@ -81,6 +82,10 @@ struct alignas(16) Smem {
     uint32_t mask[G][HIVE_MASK_WORDS];                          // legal mask being assembled
     uint8_t pinfo[G][24];        // per piece: stack height | stack index << 4 (0 = in hand)
     int32_t nlegal[G];           // legal-move count being accumulated
+    alignas(16) uint32_t cellmask[G][kCells];   // bit q: piece q stands on this cell
+    alignas(16) uint32_t adj[G][24];       // piece graph: bit j of row q = pieces q and j share a cell or touch
+    uint32_t pinmask[G];         // bit q: lifting piece q would split the hive (or it is the only piece)
+    int pin_done;                // pin waves that have published their pinmask bits
     unsigned long long feat[FULL ? G : 1][FULL ? kCells : 1];   // 56 feature bits per cell
     int done;                    // waves that have delivered their destinations
 };
@@ -113,7 +118,8 @@ struct PieceInfo {
 // own == false: mini_black_actions semantics for an enemy piece (env_hive.py:449-485)
 template <int ANT_STEPS>
 __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint32_t *occ_p, const uint32_t *topw_p,
-                                                 const uint8_t *pinfo, int q, int type, bool own, bool valid)
+                                                 const uint8_t *pinfo, const uint32_t *pinmask_p, const int *pin_done_p,
+                                                 int q, int type, bool own, bool valid)
 {
     PieceInfo out;
     const unsigned turn = state_byte(st, 33);
@@ -142,29 +148,11 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     const BB nsrc = on_board ? bb_load(d_tables.nmask[c]) : bb_zero();      // the six neighbours of src
     BB nocc;                                                                // neighbours(occ)
 
-    // ---- one-hive test (move_checker.py:58-83 / env_hive.py:509-530): flood the hive without
-    // the mover from one of its neighbours until every neighbour is reached or nothing grows.
-    // The piece's own flood (Ant reach, Grasshopper line flood, Spider first steps) runs in the
-    // SAME loop, speculatively for every top piece: two independent dependency chains per
-    // iteration, and the trip count is the max of the two floods instead of their sum.
+    // The one-hive test (move_checker.py:58-83 / env_hive.py:509-530) is not made here: the pin waves
+    // (pin_phase below) decide it for every piece of the workgroup on the 22-node piece graph while
+    // this wave floods; `pinned` is picked up from LDS once the piece's own rule is done.  The piece
+    // floods (Ant reach, Grasshopper line flood, Spider steps) run speculatively for every top piece.
     int dbg_it = 0; (void)dbg_it;
-    BB target = bb_and(nsrc, occp);
-    const bool has_nb = bb_any(target);
-    bool pinned = on_top && !stacked && !has_nb;    // lone piece: empty board => False
-    bool act = on_top && !stacked && has_nb;
-    BB reach = bb_lowest(target);
-    // two expansions per convergence test (the reductions and the loop branch cost as much as a step)
-#define HIVE_FLOOD_STEP()                                                                 \
-    if (act) {                                                                            \
-        BB nx = reach;                                                                    \
-        HIVE_UNROLL for (int u_ = 0; u_ < HIVE_HIVE_STEPS; ++u_)                          \
-            nx = bb_or(nx, bb_and(bb_neighbours(nx), occp));                              \
-        bool covered = !bb_any(bb_andn(target, nx));                                      \
-        bool fixed = bb_eq(nx, reach);                                                    \
-        reach = nx;                                                                       \
-        if (covered) act = false;                                                         \
-        else if (fixed) { act = false; pinned = true; }                                   \
-    }
 
     // ---- piece rule (pieces.py) on the board with the mover lifted
     BB rule = bb_zero();
@@ -174,9 +162,8 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
         BB Lo = bb_and(L, occ);
         BB V = srcbit;
         bool ga = on_top;
-        while (__any(ga || act)) {
+        while (__any(ga)) {
             HIVE_COUNT_ITER();
-            HIVE_FLOOD_STEP()
             if (ga) {
                 BB n1 = bb_or(V, bb_and(bb_neighbours(V), Lo));
                 BB nx = bb_or(n1, bb_and(bb_neighbours(n1), Lo));
@@ -192,14 +179,12 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
         SlideCtx ctx = make_slide_ctx(occp, S);
         nocc = bb_or(ctx.nocc, nsrc);            // N(occ) = N(occ without the mover) | N(mover)
         if (type == T_QUEEN) {
-            while (__any(act)) { HIVE_COUNT_ITER(); HIVE_FLOOD_STEP() }
             rule = slide_step(ctx, srcbit);                       // pieces.py:35-44
         } else if (type == T_ANT) {
             BB R = srcbit;                                        // pieces.py:59-63, move_checker.py:217-246
             bool aa = on_top;
-            while (__any(aa || act)) {
+            while (__any(aa)) {
                 HIVE_COUNT_ITER();
-                HIVE_FLOOD_STEP()
                 if (aa) {
                     BB nx = R;
                     HIVE_UNROLL for (int u = 0; u < ANT_STEPS; ++u) nx = bb_or(nx, slide_step(ctx, nx));
@@ -218,9 +203,8 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 BB A = slide_step(ctx, srcbit);
                 BB acc = bb_zero();
                 bool sa = on_top && bb_any(A);
-                while (__any(sa || act)) {
+                while (__any(sa)) {
                     HIVE_COUNT_ITER();
-                    HIVE_FLOOD_STEP()
                     if (sa) {
                         BB a = bb_lowest(A);
                         A = bb_andn(A, a);
@@ -235,7 +219,6 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 rule = bb_andn(acc, veto);
             } else {
                 // Beetle, pieces.py:100-113 + move_checker.py:201-209
-                while (__any(act)) { HIVE_COUNT_ITER(); HIVE_FLOOD_STEP() }
                 BB Q1 = slide_raw(ctx, srcbit);
                 BB Q0 = shift_dirs(bb_andn(bb_andn(srcbit, ctx.cs[0]), b0), bb_andn(bb_andn(srcbit, ctx.cs[1]), b1),
                                    bb_andn(bb_andn(srcbit, ctx.cs[2]), b2), bb_andn(bb_andn(srcbit, ctx.cs[3]), b3),
@@ -245,7 +228,6 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
             }
         }
     }
-#undef HIVE_FLOOD_STEP
 #ifdef HIVE_DBG_ITERS
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&d_iters[type], (unsigned long long)dbg_it);
@@ -254,6 +236,10 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
         if (dbg_it < 32) atomicAdd(&d_hist[type][dbg_it], 1ull);
     }
 #endif
+    // the verdict of the pin waves (they run concurrently with the loops above and are much shorter)
+    while (__hip_atomic_load(pin_done_p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kPinWaves)
+        __builtin_amdgcn_s_sleep(1);
+    const bool pinned = ((*pinmask_p >> q) & 1u) != 0u;
     const bool movable = on_top && !pinned;
 
     // ---- next_move_tiles (env_hive.py:66-69,150-161)
@@ -309,6 +295,59 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     out.on_top = on_top;
     out.pinned = pinned;
     return out;
+}
+
+// ------------------------------------------------------------------ one-hive test on the piece graph
+// move_does_not_break_hive (move_checker.py:58-83, env_hive.py:509-530): lift the top piece of src,
+// BFS over the occupied cells, connected?  Only an unstacked top piece can change the occupancy, and
+// cells are connected exactly when the pieces standing on them are (pieces sharing a cell or on
+// touching cells are neighbours), so the test runs on the <= 22-node piece graph instead of 144-cell
+// boards: ONE LANE per (board, piece) -- 64 items per wave instead of 16 quads -- holds the 22
+// adjacency rows of its board in registers and floods a 22-bit reach mask with alternating
+// ascending / descending Gauss-Seidel sweeps (two instructions per row) until every neighbour of
+// the lifted piece is reached (free) or nothing grows (pinned).
+template <bool FULL>
+__device__ __forceinline__ void pin_phase(Smem<FULL> &sm, int wave, int lane)
+{
+    constexpr int G = Smem<FULL>::G;
+    const int item = wave * 64 + lane;                 // 176 items: G boards x (FULL ? 22 : 11) pieces
+    const int per = FULL ? 22 : 11;
+    int b = item / per;
+    const bool ok = b < G;
+    if (!ok) b = G - 1;
+    int q = item - (item / per) * per;
+    if (!FULL) q += (state_byte(sm.state[b], 33) & 1u) ? 0 : 11;      // pieces of the side to move
+    const unsigned pi = sm.pinfo[b][q];
+    const unsigned h = pi & 15u, lv = pi >> 4;
+    const bool lifts = ok && h == 1u && lv == 0u;      // on the board, alone on its cell
+    const uint32_t notq = ~(1u << q);
+    uint32_t a[24];
+    HIVE_UNROLL for (int i = 0; i < 6; ++i) {
+        const uint4 r = reinterpret_cast<const uint4 *>(sm.adj[b])[i];
+        a[4 * i] = r.x & notq; a[4 * i + 1] = r.y & notq; a[4 * i + 2] = r.z & notq; a[4 * i + 3] = r.w & notq;
+    }                                                  // nothing floods through the lifted piece
+    const uint32_t target = sm.adj[b][q];              // its neighbours
+    bool pinned = lifts && target == 0u;               // the only piece on the board: "empty board => False"
+    bool act = lifts && target != 0u;
+    uint32_t reach = target & (0u - target);
+#ifdef HIVE_ABL_NOPINLOOP
+    act = false;
+#endif
+    while (__any(act)) {
+        if (act) {
+            uint32_t nx = reach;
+            HIVE_UNROLL for (int i = 0; i < 22; ++i) nx |= a[i] & (uint32_t)(((int)(nx << (31 - i))) >> 31);
+            HIVE_UNROLL for (int i = 21; i >= 0; --i) nx |= a[i] & (uint32_t)(((int)(nx << (31 - i))) >> 31);
+            const bool covered = (target & ~nx) == 0u;
+            const bool fixed = nx == reach;
+            reach = nx;
+            if (covered) act = false;
+            else if (fixed) { act = false; pinned = true; }
+        }
+    }
+    if (pinned) atomicOr(&sm.pinmask[b], 1u << q);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(&sm.pin_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // cell test on a lane-distributed board (result replicated over the quad)
@@ -372,8 +411,10 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     for (int i = tid; i < G * 6; i += nthreads) reinterpret_cast<uint32_t *>(&sm.pinfo[0][0])[i] = 0u;
     if (FULL)
         for (int i = tid; i < G * kCells; i += nthreads) (&sm.feat[0][0])[i] = 0ull;
-    if (tid == 0) sm.done = 0;
-    if (tid < G) sm.nlegal[tid] = 0;
+    for (int i = tid; i < G * kCells / 4; i += nthreads)
+        reinterpret_cast<uint4 *>(&sm.cellmask[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) { sm.done = 0; sm.pin_done = 0; }
+    if (tid < G) { sm.nlegal[tid] = 0; sm.pinmask[tid] = 0u; }
     __syncthreads();
 
     // occupancy and top-colour boards: every (board, piece) pair ORs its bit in
@@ -390,8 +431,29 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
             cell_word_bit(c, wi, bit);
             atomicOr(&sm.occ[b][wi], 1u << bit);
             if (lv + 1u == h && q < 11) atomicOr(&sm.topw[b][wi], 1u << bit);
+            atomicOr(&sm.cellmask[b][c], 1u << q);
             sm.pinfo[b][q] = (uint8_t)(h | (lv << 4));
         }
+    }
+    __syncthreads();
+
+    // piece graph: row q = the pieces on q's cell and on its six neighbour cells
+#ifdef HIVE_ABL_NOADJ
+    for (int pi = tid; pi < 0; pi += nthreads) {
+#else
+    for (int pi = tid; pi < G * 22; pi += nthreads) {
+#endif
+        int b = pi % G, q = pi / G;
+        unsigned c = state_byte(sm.state[b], (unsigned)q);
+        uint32_t row = 0u;
+        if (c < (unsigned)kCells) {
+            const uint2 nb = *reinterpret_cast<const uint2 *>(d_tables.nbr[c]);
+            row = sm.cellmask[b][c];
+            HIVE_UNROLL for (int k = 0; k < 6; ++k)
+                row |= sm.cellmask[b][((k < 4 ? nb.x : nb.y) >> ((k & 3) * 8)) & 0xFFu];
+            row &= ~(1u << q);
+        }
+        sm.adj[b][q] = row;
     }
     __syncthreads();
 
@@ -409,12 +471,22 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         if (type == T_ANT) __builtin_amdgcn_s_setprio(3);
         else if (type == T_SPIDER) __builtin_amdgcn_s_setprio(2);
     }
+    if (wv < kPinWaves) {
+        // the three lightest waves (Queen, Beetles) settle the one-hive question for the whole workgroup first
+        if (PRIO) __builtin_amdgcn_s_setprio(3);
+        pin_phase<FULL>(sm, wv, lane);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+    }
     int q;
     bool own;
     if (!FULL) { q = stm * 11 + wv; own = true; }
     else { int col = item >> 3; q = col * 11 + wv; own = (col == stm); }
     // latency-tuned launches also take three Ant expansions per convergence test (fewer loop trips)
-    PieceInfo pc = piece_dests<PRIO ? 3 : HIVE_ANT_STEPS>(st, sm.occ[bl], sm.topw[bl], sm.pinfo[bl], q, type, own, valid);
+#ifndef HIVE_ANT_STEPS_PRIO
+#define HIVE_ANT_STEPS_PRIO 2
+#endif
+    PieceInfo pc = piece_dests<PRIO ? HIVE_ANT_STEPS_PRIO : HIVE_ANT_STEPS>(st, sm.occ[bl], sm.topw[bl], sm.pinfo[bl], &sm.pinmask[bl], &sm.pin_done, q,
+                                                           type, own, valid);
     HIVE_STAMP(1);
     if (own && (mask != nullptr || count != nullptr)) {
         scatter_dests(sm.mask[bl], pc.D, wv);
@@ -723,7 +795,10 @@ int hive_device_count(void)
     return c;
 }
 
-constexpr int kPrioMaxBoards = 16384;      // measured crossover of the s_setprio variant (tools/ablate.py)
+#ifndef HIVE_PRIO_MAX
+#define HIVE_PRIO_MAX 16384
+#endif
+constexpr int kPrioMaxBoards = HIVE_PRIO_MAX;      // measured crossover of the s_setprio variant (tools/ablate.py)
 
 static int launch_pieces(const HiveBoard *boards, int n, uint32_t *mask, int32_t *count, int16_t *list,
                          hipStream_t stream)
