@@ -86,6 +86,7 @@ struct alignas(16) Smem {
     alignas(16) uint32_t adj[G][24];       // piece graph: bit j of row q = pieces q and j share a cell or touch
     uint32_t pinmask[G];         // bit q: lifting piece q would split the hive (or it is the only piece)
     int pin_done;                // pin waves that have published their pinmask bits
+    int adj_done;                // pin waves that have written their share of the adjacency rows
     unsigned long long feat[FULL ? G : 1][FULL ? kCells : 1];   // 56 feature bits per cell
     int done;                    // waves that have delivered their destinations
 };
@@ -310,6 +311,26 @@ template <bool FULL>
 __device__ __forceinline__ void pin_phase(Smem<FULL> &sm, int wave, int lane)
 {
     constexpr int G = Smem<FULL>::G;
+    // piece graph first: row q = the pieces on q's cell and on its six neighbour cells (G x 22 rows, two per lane);
+    // the other eight waves are already at their piece work and never wait for this
+    for (int r = wave * 64 + lane; r < G * 22; r += kPinWaves * 64) {
+        const int rb = r / 22, rq = r - rb * 22;
+        const unsigned c = state_byte(sm.state[rb], (unsigned)rq);
+        uint32_t row = 0u;
+        if (c < (unsigned)kCells) {
+            const uint2 nb = *reinterpret_cast<const uint2 *>(d_tables.nbr[c]);
+            row = sm.cellmask[rb][c];
+            HIVE_UNROLL for (int k = 0; k < 6; ++k)
+                row |= sm.cellmask[rb][((k < 4 ? nb.x : nb.y) >> ((k & 3) * 8)) & 0xFFu];
+            row &= ~(1u << rq);
+        }
+        sm.adj[rb][rq] = row;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(&sm.adj_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(&sm.adj_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kPinWaves)
+        __builtin_amdgcn_s_sleep(1);
+
     const int item = wave * 64 + lane;                 // 176 items: G boards x (FULL ? 22 : 11) pieces
     const int per = FULL ? 22 : 11;
     int b = item / per;
@@ -356,6 +377,7 @@ __device__ __forceinline__ bool bb_test(BB x, unsigned cell) { return bb_any(bb_
 // OR the set cells of this lane's two words of D into the board's 1584-bit mask: bit cell*11+slot
 __device__ __forceinline__ void scatter_dests(uint32_t *mrow, BB D, int slot)
 {
+    // (walking lo and hi together under one loop measured slower: both halves then issue on every trip)
     const int l = quad_lane();
     HIVE_UNROLL for (int half = 0; half < 2; ++half) {
         uint32_t w = half ? D.hi : D.lo;
@@ -413,7 +435,7 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         for (int i = tid; i < G * kCells; i += nthreads) (&sm.feat[0][0])[i] = 0ull;
     for (int i = tid; i < G * kCells / 4; i += nthreads)
         reinterpret_cast<uint4 *>(&sm.cellmask[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid == 0) { sm.done = 0; sm.pin_done = 0; }
+    if (tid == 0) { sm.done = 0; sm.pin_done = 0; sm.adj_done = 0; }
     if (tid < G) { sm.nlegal[tid] = 0; sm.pinmask[tid] = 0u; }
     __syncthreads();
 
@@ -434,26 +456,6 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
             atomicOr(&sm.cellmask[b][c], 1u << q);
             sm.pinfo[b][q] = (uint8_t)(h | (lv << 4));
         }
-    }
-    __syncthreads();
-
-    // piece graph: row q = the pieces on q's cell and on its six neighbour cells
-#ifdef HIVE_ABL_NOADJ
-    for (int pi = tid; pi < 0; pi += nthreads) {
-#else
-    for (int pi = tid; pi < G * 22; pi += nthreads) {
-#endif
-        int b = pi % G, q = pi / G;
-        unsigned c = state_byte(sm.state[b], (unsigned)q);
-        uint32_t row = 0u;
-        if (c < (unsigned)kCells) {
-            const uint2 nb = *reinterpret_cast<const uint2 *>(d_tables.nbr[c]);
-            row = sm.cellmask[b][c];
-            HIVE_UNROLL for (int k = 0; k < 6; ++k)
-                row |= sm.cellmask[b][((k < 4 ? nb.x : nb.y) >> ((k & 3) * 8)) & 0xFFu];
-            row &= ~(1u << q);
-        }
-        sm.adj[b][q] = row;
     }
     __syncthreads();
 
