@@ -15,7 +15,7 @@ HIVE_CELLS = 144
 HIVE_PIECES = 22
 HIVE_ACTIONS = 1584
 HIVE_PLANES = 56
-HIVE_MASK_WORDS = 50
+HIVE_MASK_WORDS = 66
 HIVE_LIST_CAP = 256
 HIVE_IN_HAND = 255
 BOARD_BYTES = 64

@@ -71,7 +71,7 @@ class BoardBatch:
 
     # ---- GamePlay.actions
     def legal(self, want_list=False):
-        """-> (mask uint32 [n,50] viewed as int32, count int32 [n], list int16 [n,256] or None)."""
+        """-> (mask uint32 [n,66] viewed as int32 (11 destination boards per position), count int32 [n], list int16 [n,256] or None)."""
         self._sync_stream()
         mask = torch.empty((self.n, HIVE_MASK_WORDS), dtype=torch.int32, device=self.device)
         count = torch.empty((self.n,), dtype=torch.int32, device=self.device)

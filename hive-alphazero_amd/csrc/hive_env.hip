@@ -79,7 +79,6 @@ struct alignas(16) Smem {
     uint32_t state[G][16];       // HiveBoard records
     uint32_t occ[G][6];          // cells with at least one piece
     uint32_t topw[G][6];         // cells whose top piece is white
-    uint32_t mask[G][HIVE_MASK_WORDS];                          // legal mask being assembled
     uint8_t pinfo[G][24];        // per piece: stack height | stack index << 4 (0 = in hand)
     int32_t nlegal[G];           // legal-move count being accumulated
     alignas(16) uint32_t cellmask[G][kCells];   // bit q: piece q stands on this cell
@@ -374,23 +373,6 @@ __device__ __forceinline__ void pin_phase(Smem<FULL> &sm, int wave, int lane)
 // cell test on a lane-distributed board (result replicated over the quad)
 __device__ __forceinline__ bool bb_test(BB x, unsigned cell) { return bb_any(bb_and(x, bb_bit(cell))); }
 
-// OR the set cells of this lane's two words of D into the board's 1584-bit mask: bit cell*11+slot
-__device__ __forceinline__ void scatter_dests(uint32_t *mrow, BB D, int slot)
-{
-    // (walking lo and hi together under one loop measured slower: both halves then issue on every trip)
-    const int l = quad_lane();
-    HIVE_UNROLL for (int half = 0; half < 2; ++half) {
-        uint32_t w = half ? D.hi : D.lo;
-        const unsigned row0 = 4u * (unsigned)l + 2u * (unsigned)half;
-        while (w) {
-            unsigned bit = __builtin_ctz(w);
-            w &= w - 1u;
-            unsigned a = ((row0 + (bit >> 4)) * 12u + (bit & 15u)) * 11u + (unsigned)slot;
-            atomicOr(&mrow[a >> 5], 1u << (a & 31u));
-        }
-    }
-}
-
 // The piece kernel.  FULL = false: legal mask/count of the side to move (GamePlay.actions).
 // FULL = true: both colours; additionally the 56 feature bits per cell (planes 0-35, 44-55 of
 // GamePlay.make_state_value; history planes 36-43 and plane 31 are added by hive_expand_kernel).
@@ -429,7 +411,6 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         (&sm.occ[0][0])[i] = 0u;
         (&sm.topw[0][0])[i] = 0u;
     }
-    for (int i = tid; i < G * HIVE_MASK_WORDS; i += nthreads) (&sm.mask[0][0])[i] = 0u;
     for (int i = tid; i < G * 6; i += nthreads) reinterpret_cast<uint32_t *>(&sm.pinfo[0][0])[i] = 0u;
     if (FULL)
         for (int i = tid; i < G * kCells; i += nthreads) (&sm.feat[0][0])[i] = 0ull;
@@ -491,7 +472,10 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
                                                            type, own, valid);
     HIVE_STAMP(1);
     if (own && (mask != nullptr || count != nullptr)) {
-        scatter_dests(sm.mask[bl], pc.D, wv);
+        // the legal set leaves as it is: slot wv's destination board, two words per lane, straight to HBM
+        if (valid && mask != nullptr && (lane & 3) < 3)
+            *reinterpret_cast<uint2 *>(mask + (gbase + bl) * HIVE_MASK_WORDS + wv * 6 + 2 * (lane & 3)) =
+                make_uint2(pc.D.lo, pc.D.hi);
         const int nd = __popc(pc.D.lo) + __popc(pc.D.hi);       // destination sets of different pieces are disjoint
         if (nd) atomicAdd(&sm.nlegal[bl], nd);
     }
@@ -550,14 +534,6 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     const int nb = (int)((n - gbase) < G ? (n - gbase) : G);
-    if (mask != nullptr) {
-        // G boards x 200 bytes are one contiguous, 16-byte aligned block on both sides
-        const uint4 *src = reinterpret_cast<const uint4 *>(&sm.mask[0][0]);
-        uint4 *dst = reinterpret_cast<uint4 *>(mask + gbase * HIVE_MASK_WORDS);
-        const int n16 = nb * HIVE_MASK_WORDS / 4, rem = nb * HIVE_MASK_WORDS - n16 * 4;
-        for (int i = lane; i < n16; i += 64) dst[i] = src[i];
-        if (lane < rem) mask[gbase * HIVE_MASK_WORDS + n16 * 4 + lane] = (&sm.mask[0][0])[n16 * 4 + lane];
-    }
     if (count != nullptr && lane < nb) count[gbase + lane] = sm.nlegal[lane];
     HIVE_STAMP(3);
     if (FULL && feat != nullptr) {
@@ -567,22 +543,33 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     }
 }
 
-// Sorted legal-id lists from the 1584-bit masks: one wave per board, the mask word IS the ballot
-// of the predicate "action 64 t + lane is legal", v_mbcnt gives each lane its slot in the list.
+// GamePlay.encode_action (env_hive.py:287-304): {slot: destination board} -> ascending action ids.
+// One wave per board: lane l of pass t asks "is action 64 t + l legal?" of the destination boards held
+// in LDS; the ballot of the answers is the id-ordered mask word, v_mbcnt gives each lane its list slot.
 __global__ void __launch_bounds__(256)
-hive_list_kernel(const unsigned long long *__restrict__ mask, int n, int16_t *__restrict__ list)
+hive_list_kernel(const uint32_t *__restrict__ mask, int n, int16_t *__restrict__ list)
 {
-    const int lane = threadIdx.x & 63;
-    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ uint32_t dest[4][HIVE_MASK_WORDS + 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long b = (long long)blockIdx.x * 4 + wv;
     if (b >= n) return;
-    const unsigned long long *m = mask + b * 25;
+    const uint32_t *m = mask + b * HIVE_MASK_WORDS;
+    dest[wv][lane] = m[lane];
+    if (lane < HIVE_MASK_WORDS - 64) dest[wv][64 + lane] = m[64 + lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // same-wave LDS traffic only: program order suffices
+    __builtin_amdgcn_wave_barrier();
     int16_t *row = list + b * HIVE_LIST_CAP;
     int total = 0;
     for (int t = 0; t < 25; ++t) {
-        unsigned long long w = m[t];
-        if ((w >> lane) & 1ull) {
+        const unsigned a = 64u * (unsigned)t + (unsigned)lane;
+        const unsigned cell = a / 11u, slot = a - cell * 11u;
+        unsigned wi, bit;
+        cell_word_bit(cell, wi, bit);
+        const bool legal = a < (unsigned)HIVE_ACTIONS && ((dest[wv][slot * 6u + wi] >> bit) & 1u);
+        const unsigned long long w = __ballot(legal);
+        if (legal) {
             int p = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(w >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)w, 0u));
-            if (p < HIVE_LIST_CAP) row[p] = (int16_t)(t * 64 + lane);
+            if (p < HIVE_LIST_CAP) row[p] = (int16_t)a;
         }
         total += __popcll(w);
     }
@@ -686,8 +673,10 @@ __global__ void hive_step_kernel(HiveBoard *__restrict__ boards, HiveHistory *__
     if (a == -2) return;
     if (a < -2 || a >= HIVE_ACTIONS) { if (illegal_count) atomicAdd(illegal_count, 1ull); return; }
     if (a >= 0 && legal_mask != nullptr) {
-        uint32_t wmask = legal_mask[(long long)b * HIVE_MASK_WORDS + (a >> 5)];
-        if (!((wmask >> (a & 31)) & 1u)) { if (illegal_count) atomicAdd(illegal_count, 1ull); return; }
+        if (!HIVE_MASK_TEST(legal_mask + (long long)b * HIVE_MASK_WORDS, a)) {
+            if (illegal_count) atomicAdd(illegal_count, 1ull);
+            return;
+        }
     }
     apply_action(&boards[b], hist ? &hist[b] : nullptr, a);
 }
@@ -816,7 +805,7 @@ static int launch_pieces(const HiveBoard *boards, int n, uint32_t *mask, int32_t
     HIP_TRY(hipGetLastError());
     if (list != nullptr) {
         hipLaunchKernelGGL(hive_list_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream,
-                           reinterpret_cast<const unsigned long long *>(mask), n, list);
+                           mask, n, list);
         HIP_TRY(hipGetLastError());
     }
     return HIVE_OK;

@@ -234,7 +234,7 @@ search_select_kernel(SearchDev S, int slot, unsigned long long sim, HiveBoard *_
 // expansion (solo_play.py:188-197,304-313) + backup (solo_play.py:217-247)
 __global__ void __launch_bounds__(256)
 search_backup_kernel(SearchDev S, int slot, const HiveBoard *__restrict__ leaf_boards,
-                     const HiveHistory *__restrict__ leaf_hist, const unsigned long long *__restrict__ leaf_mask,
+                     const HiveHistory *__restrict__ leaf_hist, const uint32_t *__restrict__ leaf_mask,
                      const int8_t *__restrict__ over, const int8_t *__restrict__ winner, const float *__restrict__ p,
                      const float *__restrict__ v)
 {
@@ -282,19 +282,23 @@ search_backup_kernel(SearchDev S, int slot, const HiveBoard *__restrict__ leaf_b
         const long long eb = (nbase + id) * EC;
         int ne = 0;
         if (!term) {
-            const unsigned long long *m = leaf_mask + (long long)g * 25;
+            // the leaf's legal set arrives as 11 destination boards (hive_abi.h); lane l of pass t owns action 64 t + l,
+            // so the ballots below are the id-ordered mask words and the edges come out in ascending action order
+            const uint32_t *m = leaf_mask + (long long)g * HIVE_MASK_WORDS;
             const float *pg = p + (long long)g * HIVE_ACTIONS;
+            unsigned legal_bits = 0u;                       // bit t: action 64 t + lane is legal
             float tot = 0.f;
             for (int t = 0; t < 25; ++t) {
-                unsigned long long w = m[t];
-                if ((w >> lane) & 1ull) tot += pg[t * 64 + lane];
+                const int a = t * 64 + lane;
+                if (a < HIVE_ACTIONS && HIVE_MASK_TEST(m, a)) { legal_bits |= 1u << t; tot += pg[a]; }
             }
             tot = wave_sum(tot) + 1e-8f;                    // solo_play.py:305-312
             const float inv = 1.0f / tot;
             int total = 0;
             for (int t = 0; t < 25; ++t) {
-                unsigned long long w = m[t];
-                if ((w >> lane) & 1ull) {
+                const bool mine = (legal_bits >> t) & 1u;
+                const unsigned long long w = __ballot(mine);
+                if (mine) {
                     int pos = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(w >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)w, 0u));
                     if (pos < EC) {
                         int a = t * 64 + lane;
@@ -566,7 +570,7 @@ int hive_search_backup(HiveSearch *s, int slot, const HiveBoard *leaf_boards, co
         return hive::set_error(HIVE_E_ARG, "bad argument");
     S_TRY(hipSetDevice(s->device));
     hipLaunchKernelGGL(search_backup_kernel, wave_grid(s->d.G), dim3(256), 0, s->stream, s->d, slot, leaf_boards, leaf_hist,
-                       reinterpret_cast<const unsigned long long *>(leaf_mask), over, winner, p, v);
+                       leaf_mask, over, winner, p, v);
     S_TRY(hipGetLastError());
     return HIVE_OK;
 }

@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import BF16, F16, F32, HWC, check, load
+from ._lib import BF16, F16, F32, HIVE_MASK_WORDS, HWC, check, load
 from .config import MAX_GAME_LENGTH
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -48,7 +48,7 @@ class TreeSearch:
         self.plane_dtype = plane_dtype
         self.leaf_boards = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
         self.leaf_hist = torch.zeros((n, 384), dtype=torch.uint8, device=dev)
-        self.leaf_mask = torch.zeros((n, 50), dtype=torch.int32, device=dev)
+        self.leaf_mask = torch.zeros((n, HIVE_MASK_WORDS), dtype=torch.int32, device=dev)
         self.leaf_count = torch.zeros((n,), dtype=torch.int32, device=dev)
         self.leaf_over = torch.zeros((n,), dtype=torch.int8, device=dev)
         self.leaf_winner = torch.zeros((n,), dtype=torch.int8, device=dev)

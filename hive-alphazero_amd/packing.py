@@ -65,6 +65,20 @@ def unpack_boards(rec):
 
 
 def mask_to_actions(mask_row):
-    """uint32[50] legal mask -> ascending list of action ids."""
-    bits = np.unpackbits(np.asarray(mask_row, dtype=np.uint32).view(np.uint8), bitorder="little")
-    return np.nonzero(bits[:1584])[0].tolist()
+    """uint32[66] legal set (11 destination boards, include/hive_abi.h) -> ascending list of action ids
+    (GamePlay.encode_action, env_hive.py:287-304)."""
+    w = np.asarray(mask_row, dtype=np.uint32).reshape(11, 6)
+    bits = np.unpackbits(w.view(np.uint8).reshape(11, 6, 4), axis=2, bitorder="little").reshape(11, 6, 2, 16)[..., :12]
+    on = bits.reshape(11, 144)                      # [slot][cell]: word r = rows 2r, 2r+1
+    slot, cell = np.nonzero(on)
+    return np.sort(cell * 11 + slot).tolist()
+
+
+def actions_to_mask(actions):
+    """ascending action ids -> uint32[66] destination boards (inverse of mask_to_actions)."""
+    w = np.zeros((11, 6), dtype=np.uint32)
+    for a in actions:
+        cell, slot = divmod(int(a), 11)
+        row, col = divmod(cell, 12)
+        w[slot, row >> 1] |= np.uint32(1 << (((row & 1) << 4) | col))
+    return w.reshape(66)

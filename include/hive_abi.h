@@ -36,9 +36,15 @@ extern "C" {
 #define HIVE_PIECES 22
 #define HIVE_ACTIONS 1584          /* hive_engine/config.py:10 ACTION_SPACE */
 #define HIVE_PLANES 56             /* hive_engine/config.py:20 STATE_FEATURES */
-#define HIVE_MASK_WORDS 50         /* 1584 bits padded to 25 x u64 = 50 x u32 */
+#define HIVE_SLOTS 11               /* piece slots per colour: Q B B S S G G G A A A (inventory_frame.py:47-99) */
+#define HIVE_MASK_WORDS 66         /* legal set = 11 slots x one 6-word destination board (see hive_batch_legal) */
 #define HIVE_IN_HAND 255
 #define HIVE_LIST_CAP 256          /* capacity of one compacted legal-id row */
+
+/* where action id a = (row*12 + col)*11 + slot sits inside one board's legal mask (see hive_batch_legal) */
+#define HIVE_MASK_WORD(a) (((a) % HIVE_SLOTS) * 6 + ((((a) / HIVE_SLOTS) / 12) >> 1))
+#define HIVE_MASK_BIT(a) (((((a) / HIVE_SLOTS) / 12 & 1) << 4) | (((a) / HIVE_SLOTS) % 12))
+#define HIVE_MASK_TEST(mask_row, a) (((mask_row)[HIVE_MASK_WORD(a)] >> HIVE_MASK_BIT(a)) & 1u)
 
 enum {
     HIVE_OK = 0,
@@ -104,11 +110,15 @@ int hive_batch_step(HiveBatch *h, const int32_t *actions, int sync);
 int hive_batch_illegal_count(HiveBatch *h, int64_t *count /* host */);
 
 /* GamePlay.actions (env_hive.py:182-183, 196-304): legal set of the side to move.
- * mask  = device uint32[n][HIVE_MASK_WORDS], bit a = action a legal (may be NULL);
+ * mask  = device uint32[n][HIVE_MASK_WORDS]: the legal set in the form GamePlay.pre_actions builds it
+ *         (env_hive.py:196-285, {piece slot: [destination tiles]}): words 6s .. 6s+5 are the destination
+ *         board of the mover's piece slot s -- word r holds rows 2r (bits 0-11, bit = column) and 2r+1
+ *         (bits 16-27), the same bitboard words HiveHistory uses; action a = cell*11 + s is legal iff
+ *         HIVE_MASK_TEST(row, a) (may be NULL);
  * count = device int32[n] (may be NULL);
- * list  = device int16[n][HIVE_LIST_CAP], ascending action ids, -1 padded (may be NULL; in the
- *         stateless launch it needs mask != NULL); a board with more than HIVE_LIST_CAP legal
- *         ids keeps the first HIVE_LIST_CAP. */
+ * list  = device int16[n][HIVE_LIST_CAP]: GamePlay.encode_action (env_hive.py:287-304) of that set, i.e. the
+ *         ascending action ids GamePlay.actions() returns, -1 padded (may be NULL; in the stateless launch it
+ *         needs mask != NULL); a board with more than HIVE_LIST_CAP legal ids keeps the first HIVE_LIST_CAP. */
 int hive_batch_legal(HiveBatch *h, uint32_t *mask, int32_t *count, int16_t *list);
 
 /* GamePlay.encode_board (env_hive.py:306-485): the 56 planes from the mover's side. */
@@ -133,7 +143,7 @@ int hive_encode_launch(const HiveBoard *boards, const HiveHistory *hist, int n, 
 
 /* GamePlay.game_is_over over caller-owned records. */
 int hive_terminal_launch(const HiveBoard *boards, int n, int8_t *over, int8_t *winner, void *stream);
-/* GamePlay.move over caller-owned records: actions as hive_batch_step; legal_mask (uint32[n][50]) may be
+/* GamePlay.move over caller-owned records: actions as hive_batch_step; legal_mask (uint32[n][HIVE_MASK_WORDS]) may be
  * NULL when the actions are known to be legal (they come out of the search's own edge lists). */
 int hive_step_launch(HiveBoard *boards, HiveHistory *hist, int n, const int32_t *actions, const uint32_t *legal_mask,
                      void *stream);

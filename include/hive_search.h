@@ -59,7 +59,7 @@ int hive_search_set_roots(HiveSearch *s, const HiveBoard *boards, const HiveHist
  * evaluate (untouched for games whose path ended in a known terminal node or a collision). */
 int hive_search_select(HiveSearch *s, int slot, HiveBoard *leaf_boards, HiveHistory *leaf_hist);
 
-/* Expansion + backup for slot `slot`.  leaf_mask = uint32[games][50] legal masks of the leaves,
+/* Expansion + backup for slot `slot`.  leaf_mask = uint32[games][HIVE_MASK_WORDS] legal sets of the leaves (destination boards, hive_abi.h),
  * over / winner as hive_batch_terminal, p = float[games][1584] (softmax output), v = float[games]. */
 int hive_search_backup(HiveSearch *s, int slot, const HiveBoard *leaf_boards, const HiveHistory *leaf_hist,
                        const uint32_t *leaf_mask, const int8_t *over, const int8_t *winner, const float *p,

@@ -29,9 +29,10 @@ def hv():
 
 
 def _mask_rows_to_lists(mask):
+    """uint32[n][66] destination boards (hive_abi.h) -> ascending action-id lists."""
+    from hive_alphazero_amd import packing
     m = mask.cpu().numpy().view(np.uint32)
-    bits = np.unpackbits(m.view(np.uint8).reshape(m.shape[0], -1), axis=1, bitorder="little")[:, :1584]
-    return [np.nonzero(r)[0].tolist() for r in bits]
+    return [packing.mask_to_actions(r) for r in m]
 
 
 def _mode_of(rec):
@@ -281,8 +282,10 @@ def test_size_independent_properties_large_batch(hv):
     inc = (l[:, 1:] > l[:, :-1]) | ~valid[:, 1:]
     assert bool(inc.all())
     idx = torch.where(valid, l, torch.zeros_like(l)).long()
-    word = mask.gather(1, idx >> 5)
-    assert bool(((((word >> (idx & 31)) & 1) == 1) | ~valid).all())
+    cell, slot = idx // 11, idx % 11                                                   # HIVE_MASK_TEST (hive_abi.h)
+    row, col = cell // 12, cell % 12
+    word = mask.gather(1, slot * 6 + (row >> 1))
+    assert bool(((((word >> (((row & 1) << 4) | col)) & 1) == 1) | ~valid).all())
 
 
 def test_abi_argument_errors(hv):

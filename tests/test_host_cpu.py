@@ -59,10 +59,10 @@ def test_packing_roundtrip(golden_games):
     st = packing.unpack_boards(rec)
     assert st["turn"].tolist() == turn.tolist() and np.array_equal(st["pos"], pos) and np.array_equal(st["lvl"], lvl)
     assert packing.words_to_cells(packing.mask_words([0, 13, 143, 77])) == [0, 13, 77, 143]
-    m = np.zeros(50, dtype=np.uint32)
-    for a in (0, 31, 32, 858, 1583):
-        m[a >> 5] |= np.uint32(1 << (a & 31))
-    assert packing.mask_to_actions(m) == [0, 31, 32, 858, 1583]
+    ids = [0, 31, 32, 858, 1583]
+    m = packing.actions_to_mask(ids)
+    assert m.shape == (66,) and packing.mask_to_actions(m) == ids
+    assert int(m[0]) == 1 and int(m[10 * 6 + 5]) == 1 << (16 + 11)      # (slot 0, cell 0) and (slot 10, cell 143)
 
 
 def test_records_wire_format(tmp_path, golden_games):

@@ -12,7 +12,7 @@ for so in sorted(glob.glob(sys.argv[1] + "/abl_*.so")):
     res = []
     for n in SIZES:
         b = big[:n].contiguous()
-        mask = torch.empty((n, 50), dtype=torch.int32, device="cuda")
+        mask = torch.empty((n, 66), dtype=torch.int32, device="cuda")
         cnt = torch.empty((n,), dtype=torch.int32, device="cuda")
         s = torch.cuda.current_stream()
         args = (b.data_ptr(), n, mask.data_ptr(), cnt.data_ptr(), None, s.cuda_stream)

@@ -9,7 +9,7 @@ L = ctypes.CDLL(sys.argv[1])
 L.hive_movegen_launch.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
 n = 4096
 boards = playout.random_positions(n, seed=1000)
-mask = torch.empty((n, 50), dtype=torch.int32, device="cuda")
+mask = torch.empty((n, 66), dtype=torch.int32, device="cuda")
 cnt = torch.empty((n,), dtype=torch.int32, device="cuda")
 L.hive_movegen_launch(boards.data_ptr(), n, mask.data_ptr(), cnt.data_ptr(), None, None)
 torch.cuda.synchronize()
@@ -20,3 +20,21 @@ names = ["queen", "beetle", "spider", "grasshopper", "ant"]
 for t, nm in enumerate(names):
     hist = v[32 + 32 * t: 64 + 32 * t]
     print(f"{nm:12s} waves {v[8 + t]:5d}  mean trips {v[t] / max(v[8 + t], 1):5.2f}  max {v[16 + t]:3d}  hist {list(hist[:int(v[16 + t]) + 1])}")
+
+def stamps():
+    st = (ctypes.c_ulonglong * 88)()
+    assert L.hive_debug_stamps(st) == 0
+    return np.array(st[:], dtype=np.float64).reshape(11, 8)
+for _ in range(20):
+    L.hive_movegen_launch(boards.data_ptr(), n, mask.data_ptr(), cnt.data_ptr(), None, None)
+torch.cuda.synchronize()
+s0 = stamps()
+for _ in range(10):
+    L.hive_movegen_launch(boards.data_ptr(), n, mask.data_ptr(), cnt.data_ptr(), None, None)
+torch.cuda.synchronize()
+s = (stamps() - s0) / 160.0      # 16 sampled workgroups x 10 warm launches
+print("shader cycles since kernel start (mean over sampled workgroups; build with -DHIVE_DBG_STAMPS_ONLY for clean numbers):")
+print("            staged   piece work done   scattered   tail written (only the last wave of a workgroup)")
+for w in range(11):
+    print(f"  slot {w:2d}: " + "  ".join(f"{x:8.0f}" for x in s[w, :4]) + (f"   pin phase done {s[w, 4]:8.0f}" if s[w, 4] else ""))
+print(f"  mean workgroup end: {s[:, 3].sum():.0f} cycles")
