@@ -228,7 +228,7 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
             }
         }
     }
-#ifdef HIVE_DBG_ITERS
+#if defined(HIVE_DBG_ITERS) && !defined(HIVE_DBG_STAMPS_ONLY)
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&d_iters[type], (unsigned long long)dbg_it);
         atomicAdd(&d_iters[8 + type], 1ull);
@@ -458,6 +458,7 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         // the three lightest waves (Queen, Beetles) settle the one-hive question for the whole workgroup first
         if (PRIO) __builtin_amdgcn_s_setprio(3);
         pin_phase<FULL>(sm, wv, lane);
+        HIVE_STAMP(4);
         if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
     int q;
