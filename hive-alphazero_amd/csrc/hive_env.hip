@@ -32,7 +32,7 @@ namespace hive {
 __device__ const Tables d_tables = kTables;
 #ifdef HIVE_DBG_ITERS
 __device__ unsigned long long d_iters[32];
-__device__ unsigned long long d_hist[5][32];     // trips-per-wave histogram by piece type
+__device__ unsigned long long d_hist[6][32];     // trips-per-wave histogram by piece type
 __device__ unsigned long long d_stamps[11][8];
 #define HIVE_STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x % 16 == 0) atomicAdd(&d_stamps[wv][i], (unsigned long long)(clock64() - t_start)); } while (0)
 #else
@@ -353,7 +353,11 @@ __device__ __forceinline__ void pin_phase(Smem<FULL> &sm, int wave, int lane)
 #ifdef HIVE_ABL_NOPINLOOP
     act = false;
 #endif
+    int pin_trips = 0; (void)pin_trips;
     while (__any(act)) {
+#ifdef HIVE_DBG_ITERS
+        ++pin_trips;
+#endif
         if (act) {
             uint32_t nx = reach;
             HIVE_UNROLL for (int i = 0; i < 22; ++i) nx |= a[i] & (uint32_t)(((int)(nx << (31 - i))) >> 31);
@@ -365,6 +369,14 @@ __device__ __forceinline__ void pin_phase(Smem<FULL> &sm, int wave, int lane)
             else if (fixed) { act = false; pinned = true; }
         }
     }
+#if defined(HIVE_DBG_ITERS) && !defined(HIVE_DBG_STAMPS_ONLY)
+    if (lane == 0) {      // pin waves are booked as "type 5" of the trip statistics
+        atomicAdd(&d_iters[5], (unsigned long long)pin_trips);
+        atomicAdd(&d_iters[8 + 5], 1ull);
+        atomicMax(&d_iters[16 + 5], (unsigned long long)pin_trips);
+        if (pin_trips < 32) atomicAdd(&d_hist[5][pin_trips], 1ull);
+    }
+#endif
     if (pinned) atomicOr(&sm.pinmask[b], 1u << q);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) __hip_atomic_fetch_add(&sm.pin_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1048,7 +1060,7 @@ int hive_batch_import(HiveBatch *h, const HiveBoard *boards, const HiveHistory *
 int hive_debug_iters(unsigned long long *host16)
 {
     HIP_TRY(hipMemcpyFromSymbol(host16, HIP_SYMBOL(hive::d_iters), sizeof(unsigned long long) * 32));
-    HIP_TRY(hipMemcpyFromSymbol(host16 + 32, HIP_SYMBOL(hive::d_hist), sizeof(unsigned long long) * 160));
+    HIP_TRY(hipMemcpyFromSymbol(host16 + 32, HIP_SYMBOL(hive::d_hist), sizeof(unsigned long long) * 192));
     return HIVE_OK;
 }
 int hive_debug_stamps(unsigned long long *host88)

@@ -13,10 +13,10 @@ mask = torch.empty((n, 66), dtype=torch.int32, device="cuda")
 cnt = torch.empty((n,), dtype=torch.int32, device="cuda")
 L.hive_movegen_launch(boards.data_ptr(), n, mask.data_ptr(), cnt.data_ptr(), None, None)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 192)()
+buf = (ctypes.c_ulonglong * 224)()
 assert L.hive_debug_iters(buf) == 0
 v = np.array(buf[:], dtype=np.int64)
-names = ["queen", "beetle", "spider", "grasshopper", "ant"]
+names = ["queen", "beetle", "spider", "grasshopper", "ant", "pin waves"]
 for t, nm in enumerate(names):
     hist = v[32 + 32 * t: 64 + 32 * t]
     print(f"{nm:12s} waves {v[8 + t]:5d}  mean trips {v[t] / max(v[8 + t], 1):5.2f}  max {v[16 + t]:3d}  hist {list(hist[:int(v[16 + t]) + 1])}")
