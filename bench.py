@@ -22,8 +22,8 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_BOARD = 262          # 64 B HiveBoard read + 198 B (1584-bit) legal mask written, SURVEY.md 8d
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 # HBM bytes per board from the PMC passes in profiles/r01_movegen_pmc_traffic.md: (2 x FETCH_SIZE + WRITE_SIZE) KiB
-# per 4096-board launch = 1,339,392 B (gfx950 FETCH_SIZE correction applied); not measurable from inside bench.py
-MOVEGEN_TRAFFIC_BYTES_PER_BOARD = 327
+# per 4096-board launch = 1,614,848 B (gfx950 FETCH_SIZE correction applied); not measurable from inside bench.py
+MOVEGEN_TRAFFIC_BYTES_PER_BOARD = 394
 
 
 def host_cores(cap=16):
