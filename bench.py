@@ -339,7 +339,7 @@ def main():
                        "corpus": "GPU random playouts, every ply sampled, seed 1000+rank", "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": MOVEGEN_TRAFFIC_BYTES_PER_BOARD * n,
-                         "kernel": "hive_piece_kernel<false,true>", "launch_us": round(launch_us, 3),
+                         "kernel": "hive_piece_kernel<false>", "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_BOARD,
                          "note": "VALU-issue bound: 4096 boards = 256 workgroups x 11 waves, ~2.75 waves per SIMD; see saturated"},
             "overlapped_4_streams": overlapped,

@@ -390,7 +390,7 @@ __device__ __forceinline__ bool bb_test(BB x, unsigned cell) { return bb_any(bb_
 // GamePlay.make_state_value; history planes 36-43 and plane 31 are added by hive_expand_kernel).
 // There is no barrier after the piece work: each wave ORs its results into LDS and leaves; the
 // last wave to finish writes the workgroup's boards out.
-template <bool FULL, bool PRIO>
+template <bool FULL>
 __global__ void __launch_bounds__(NW * 64, FULL ? 5 : HIVE_PIECE_WPE)
 hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restrict__ mask,
                   int32_t *__restrict__ count, unsigned long long *__restrict__ feat)
@@ -401,7 +401,15 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     const int lane = tid & 63;
     const int item = lane >> 2;                      // quad index inside the wave
     const int bl = FULL ? (item & 7) : item;         // board of this quad inside the workgroup
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // wave -> piece slot.  Waves land on SIMD (wave id mod 4) and start in id order: waves 0-2 are the Queen and the
+    // Beetles (they run the pin phase first), then the three Ants start early on three different SIMDs, the Spiders
+    // follow, the Grasshoppers fill up: SIMD 0 = Q A0 G2, 1 = B0 A1 G0, 2 = B1 S1 G1, 3 = A2 S0.  Measured against the
+    // identity map: -7 % at 1 M boards, and as fast at 4096 boards as s_setprio-raised Ant/Spider waves were.
+#ifndef HIVE_WAVE_SLOTS
+#define HIVE_WAVE_SLOTS 0x6573498A210ull      /* hex digit w (lowest = wave 0) = piece slot of wave w */
+#endif
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = (int)((HIVE_WAVE_SLOTS >> (4 * wave_id)) & 15ull);      // the piece slot this wave works on
     const int nthreads = NW * 64;
     const long long gbase = (long long)blockIdx.x * G;
 #ifdef HIVE_DBG_ITERS
@@ -459,29 +467,16 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     const unsigned turn = state_byte(st, 33);
     const int stm = (turn & 1u) ? 0 : 1;
     const int type = slot_type(wv);
-    if (PRIO) {
-        // small batches (<= 1 workgroup per CU): the Ant and Spider waves are the critical path, let them win the
-        // issue arbitration against the light waves sharing their SIMD (-10 % at 4096 boards; above ~16 K boards
-        // starving the light waves costs throughput, so large launches use PRIO = false)
-        if (type == T_ANT) __builtin_amdgcn_s_setprio(3);
-        else if (type == T_SPIDER) __builtin_amdgcn_s_setprio(2);
-    }
-    if (wv < kPinWaves) {
+    if (wave_id < kPinWaves) {
         // the three lightest waves (Queen, Beetles) settle the one-hive question for the whole workgroup first
-        if (PRIO) __builtin_amdgcn_s_setprio(3);
-        pin_phase<FULL>(sm, wv, lane);
+        pin_phase<FULL>(sm, wave_id, lane);
         HIVE_STAMP(4);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
     int q;
     bool own;
     if (!FULL) { q = stm * 11 + wv; own = true; }
     else { int col = item >> 3; q = col * 11 + wv; own = (col == stm); }
-    // latency-tuned launches also take three Ant expansions per convergence test (fewer loop trips)
-#ifndef HIVE_ANT_STEPS_PRIO
-#define HIVE_ANT_STEPS_PRIO 2
-#endif
-    PieceInfo pc = piece_dests<PRIO ? HIVE_ANT_STEPS_PRIO : HIVE_ANT_STEPS>(st, sm.occ[bl], sm.topw[bl], sm.pinfo[bl], &sm.pinmask[bl], &sm.pin_done, q,
+    PieceInfo pc = piece_dests<HIVE_ANT_STEPS>(st, sm.occ[bl], sm.topw[bl], sm.pinfo[bl], &sm.pinmask[bl], &sm.pin_done, q,
                                                            type, own, valid);
     HIVE_STAMP(1);
     if (own && (mask != nullptr || count != nullptr)) {
@@ -799,22 +794,13 @@ int hive_device_count(void)
     return c;
 }
 
-#ifndef HIVE_PRIO_MAX
-#define HIVE_PRIO_MAX 16384
-#endif
-constexpr int kPrioMaxBoards = HIVE_PRIO_MAX;      // measured crossover of the s_setprio variant (tools/ablate.py)
-
 static int launch_pieces(const HiveBoard *boards, int n, uint32_t *mask, int32_t *count, int16_t *list,
                          hipStream_t stream)
 {
     if (n <= 0 || boards == nullptr) return fail(HIVE_E_ARG, "movegen: n <= 0 or boards == NULL");
     if (list != nullptr && mask == nullptr) return fail(HIVE_E_ARG, "movegen: the id list needs the mask buffer too");
-    if (n <= kPrioMaxBoards)
-        hipLaunchKernelGGL((hive_piece_kernel<false, true>), dim3((unsigned)((n + 15) / 16)), dim3(NW * 64), 0, stream,
-                           boards, n, mask, count, (unsigned long long *)nullptr);
-    else
-        hipLaunchKernelGGL((hive_piece_kernel<false, false>), dim3((unsigned)((n + 15) / 16)), dim3(NW * 64), 0, stream,
-                           boards, n, mask, count, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL((hive_piece_kernel<false>), dim3((unsigned)((n + 15) / 16)), dim3(NW * 64), 0, stream, boards, n, mask,
+                       count, (unsigned long long *)nullptr);
     HIP_TRY(hipGetLastError());
     if (list != nullptr) {
         hipLaunchKernelGGL(hive_list_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream,
@@ -830,12 +816,8 @@ static int launch_encode(const HiveBoard *boards, const HiveHistory *hist, int n
     if (n <= 0 || boards == nullptr || planes == nullptr || feat == nullptr)
         return fail(HIVE_E_ARG, "encode: n <= 0 or a NULL buffer");
     if (dtype < 0 || dtype > 2 || layout < 0 || layout > 1) return fail(HIVE_E_ARG, "encode: unknown dtype/layout");
-    if (n <= kPrioMaxBoards / 2)
-        hipLaunchKernelGGL((hive_piece_kernel<true, true>), dim3((unsigned)((n + 7) / 8)), dim3(NW * 64), 0, stream, boards,
-                           n, mask, count, feat);
-    else
-        hipLaunchKernelGGL((hive_piece_kernel<true, false>), dim3((unsigned)((n + 7) / 8)), dim3(NW * 64), 0, stream, boards,
-                           n, mask, count, feat);
+    hipLaunchKernelGGL((hive_piece_kernel<true>), dim3((unsigned)((n + 7) / 8)), dim3(NW * 64), 0, stream, boards, n, mask,
+                       count, feat);
     HIP_TRY(hipGetLastError());
     const long long items = (long long)n * (kCells * HIVE_PLANES / 8);
     dim3 grid((unsigned)((items + 255) / 256));
