@@ -34,6 +34,24 @@ def test_abi_library_exports_every_declared_symbol():
     assert L.hive_version().startswith(b"hive-hip")
 
 
+def test_abi_headers_are_plain_c(tmp_path):
+    """include/*.h compile as C with gcc (struct sizes pinned by _Static_assert) and the HIVE_MASK_* macros address
+    the legal-set words exactly like the host-side packing helpers."""
+    exe = tmp_path / "abi_header_check"
+    cc = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                         os.path.join(ROOT, "tests", "abi_header_check.c"), "-o", str(exe)], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0 and run.stdout.strip() == "0"
+    from hive_alphazero_amd import packing
+    ids = [0, 11, 131, 132, 858, 1583]
+    m = packing.actions_to_mask(ids)
+    for a in range(1584):
+        cell, slot = divmod(a, 11)
+        row, col = divmod(cell, 12)
+        assert bool((int(m[slot * 6 + (row >> 1)]) >> (((row & 1) << 4) | col)) & 1) == (a in ids)
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
