@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "hive_search_set_roots", "hive_search_select", "hive_search_backup", "hive_search_policy",
     "hive_search_node_counts",
     # include/hive_nn.h
-    "hive_nn_conv3x3", "hive_nn_resblock",
+    "hive_nn_conv3x3", "hive_nn_resblock", "hive_nn_bn_workspace_floats", "hive_nn_bn_act_fwd", "hive_nn_bn_act_bwd",
 ]
 
 
@@ -101,6 +101,10 @@ def load():
     L.hive_search_node_counts.argtypes = [vp, vp]
     L.hive_nn_conv3x3.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp]
     L.hive_nn_resblock.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
+    f32, i64 = ctypes.c_float, ctypes.c_longlong
+    L.hive_nn_bn_workspace_floats.restype = i32
+    L.hive_nn_bn_act_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i64, i32, i32, vp]
+    L.hive_nn_bn_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
     for name in ABI_SYMBOLS:
         getattr(L, name)
     _lib = L

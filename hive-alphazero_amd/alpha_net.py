@@ -11,6 +11,8 @@ whole forward captured in a HIP graph per batch size.  It consumes the planes ex
 kernels emit them ([B,12,12,56] channels-last), so there is no transpose between encode and
 conv1.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -135,23 +137,105 @@ def train(net, dataset, epoch_start=0, epoch_stop=10, cpu=0, batch_size=512, lr=
     return losses_per_epoch
 
 
+def _cl_rows(t):
+    """[B,256,12,12] channels-last bf16 tensor -> (contiguous-as-[B*144][256] tensor, rows)."""
+    if t.dtype != torch.bfloat16 or not t.is_contiguous(memory_format=torch.channels_last):
+        t = t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    return t, t.shape[0] * t.shape[2] * t.shape[3]
+
+
+class _BNAct(torch.autograd.Function):
+    """Training-mode BatchNorm2d(256) [+ skip] [+ ReLU] on the hand-written HIP kernels (csrc/hive_train.hip,
+    include/hive_nn.h): bf16 channels-last activations, fp32 statistics and parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, bn, relu):
+        from . import _lib
+        L = _lib.load()
+        x, rows = _cl_rows(x)
+        res = None
+        if residual is not None:
+            res, _ = _cl_rows(residual)
+        dev = x.device
+        y = torch.empty_like(x)
+        mean = torch.empty(256, dtype=torch.float32, device=dev)
+        invstd = torch.empty(256, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.hive_nn_bn_workspace_floats(), dtype=torch.float32, device=dev)
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(L.hive_nn_bn_act_fwd(p(x), p(res), p(gamma), p(beta), p(bn.running_mean), p(bn.running_var),
+                                        float(bn.momentum), float(bn.eps), p(y), p(mean), p(invstd), p(ws), rows, 256,
+                                        int(relu), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        bn.num_batches_tracked += 1
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.relu, ctx.has_res, ctx.rows = bool(relu), residual is not None, rows
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        L = _lib.load()
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        dy, _ = _cl_rows(dy)
+        dev = x.device
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        dgamma = torch.empty(256, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(256, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.hive_nn_bn_workspace_floats(), dtype=torch.float32, device=dev)
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(L.hive_nn_bn_act_bwd(p(dy), p(x), p(y), p(gamma), p(mean), p(invstd), p(dx), p(dres), p(dgamma),
+                                        p(dbeta), p(ws), ctx.rows, 256, int(ctx.relu),
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return dx, dgamma, dbeta, dres, None, None
+
+
+def bn_act(x, bn, residual=None, relu=True):
+    """relu(bn(x) + residual) in training mode through the HIP kernels (updates bn's running statistics)."""
+    return _BNAct.apply(x, bn.weight, bn.bias, residual, bn, relu)
+
+
+class FusedTrainNet(nn.Module):
+    """ChessNet.forward for the training step on MI355X: same modules and parameters (so the optimizer, DDP and the
+    state_dict see the reference's network), but every BatchNorm + skip + ReLU of the 256-channel tower is one fused
+    HIP forward / backward (alpha_net.py:25-54); the two heads stay on the library path."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, s):
+        net = self.net
+        if not (net.training and s.is_cuda):      # eval mode (running statistics) and CPU runs use the modules as they are
+            return net(s)
+        s = bn_act(net.conv.conv1(s), net.conv.bn1)
+        for i in range(19):
+            blk = getattr(net, "res_%i" % i)
+            out = bn_act(blk.conv1(s), blk.bn1)
+            s = bn_act(blk.conv2(out), blk.bn2, residual=s)
+        return net.outblock(s)
+
+
 class Trainer:
     """Training step of alpha_net.py:117-162 laid out for MI355X (second "next" row):
     channels-last activations, bf16 autocast on the MFMA units with fp32 master weights and fp32
     loss, Adam lr 1e-3 + MultiStepLR like the reference.  With torch.distributed initialised the
     model is wrapped in DistributedDataParallel (gradient all-reduce over RCCL/xGMI, bucketed and
-    overlapped with backward by DDP); self-play itself never needs a collective."""
+    overlapped with backward by DDP); self-play itself never needs a collective.  `fused` (default: on for bf16 on a
+    GPU) routes the tower's BatchNorm + skip + ReLU through the HIP kernels of csrc/hive_train.hip (FusedTrainNet)."""
 
-    def __init__(self, net, lr=0.001, autocast_dtype=torch.bfloat16, ddp=None):
+    def __init__(self, net, lr=0.001, autocast_dtype=torch.bfloat16, ddp=None, fused=None):
         import torch.distributed as dist
         self.device = next(net.parameters()).device
         self.net = net.to(memory_format=torch.channels_last)
         self.autocast_dtype = autocast_dtype if self.device.type == "cuda" else None
         use_ddp = ddp if ddp is not None else (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-        self.model = self.net
+        self.fused = (self.autocast_dtype == torch.bfloat16) if fused is None else bool(fused)
+        if self.fused and self.autocast_dtype != torch.bfloat16:
+            raise ValueError("the fused BatchNorm kernels are bf16: use autocast_dtype=torch.bfloat16 on a GPU")
+        self.model = FusedTrainNet(self.net) if self.fused else self.net
         if use_ddp:
             ids = [self.device.index] if self.device.type == "cuda" else None
-            self.model = torch.nn.parallel.DistributedDataParallel(self.net, device_ids=ids, bucket_cap_mb=64)
+            self.model = torch.nn.parallel.DistributedDataParallel(self.model, device_ids=ids, bucket_cap_mb=64)
         self.criterion = AlphaLoss()
         self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr)
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=[100, 200, 300, 400], gamma=0.2)

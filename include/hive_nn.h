@@ -33,6 +33,22 @@ int hive_nn_conv3x3(const void *x, int cin, const void *w, const float *bias, co
 int hive_nn_resblock(const void *x, const void *w1, const float *b1, const void *w2, const float *b2, void *y,
                      int batch, void *stream);
 
+/* Training-mode BatchNorm2d + optional skip connection + optional ReLU of the 256-channel tower, forward and
+ * backward (alpha_net.py:25-54 as executed by the training step alpha_net.py:117-162), channels-last bf16:
+ *   forward : y = act( (x - mean_c) / sqrt(var_c + eps) * gamma_c + beta_c (+ residual) ), batch statistics over all
+ *             `rows` (= batch * 144) positions; running_mean / running_var (may both be NULL) are updated with
+ *             `momentum` and the unbiased variance like torch.nn.BatchNorm2d; save_mean / save_invstd f32[256] out.
+ *   backward: dx (bf16), dgamma / dbeta (f32[256]) and, when dresidual != NULL, dresidual = dy * (y > 0) (bf16) --
+ *             the gradient that flows into the skip input; y is only read when relu != 0.
+ *   workspace: device f32[hive_nn_bn_workspace_floats()], contents undefined between calls; channels must be 256. */
+int hive_nn_bn_workspace_floats(void);
+int hive_nn_bn_act_fwd(const void *x, const void *residual, const float *gamma, const float *beta, float *running_mean,
+                       float *running_var, float momentum, float eps, void *y, float *save_mean, float *save_invstd,
+                       float *workspace, long long rows, int channels, int relu, void *stream);
+int hive_nn_bn_act_bwd(const void *dy, const void *x, const void *y, const float *gamma, const float *save_mean,
+                       const float *save_invstd, void *dx, void *dresidual, float *dgamma, float *dbeta,
+                       float *workspace, long long rows, int channels, int relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

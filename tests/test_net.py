@@ -260,3 +260,82 @@ def test_trainer_ddp_world_size_2_gloo(tmp_path):
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["after"][0] == res["after"][1] != res["before"]
     assert all(np.isfinite(l) for l in res["losses"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (False, False)])
+def test_hip_bn_act_matches_torch(with_res, relu):
+    """csrc/hive_train.hip against torch.nn.BatchNorm2d (training mode, fp32 math on the same bf16 inputs):
+    output, input / skip / parameter gradients, running statistics.  Tolerances: one bf16 rounding of the output
+    (2^-8 relative) on values of order 1; the gradient sums run over 144 * batch terms in fp32."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.alpha_net import bn_act
+    torch.manual_seed(3)
+    B = 24
+    bn = torch.nn.BatchNorm2d(256).cuda()
+    ref = torch.nn.BatchNorm2d(256).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+        ref.weight.copy_(bn.weight); ref.bias.copy_(bn.bias)
+    x = (torch.randn((B, 256, 12, 12), device="cuda") * 1.7 + 0.3).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    r = torch.randn((B, 256, 12, 12), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn((B, 256, 12, 12), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x1, r1 = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    y = bn_act(x1, bn, residual=r1 if with_res else None, relu=relu)
+    y.backward(dy)
+    x2, r2 = x.float().requires_grad_(True), r.float().requires_grad_(True)
+    z = ref(x2)
+    if with_res:
+        z = z + r2
+    if relu:
+        z = torch.relu(z)
+    # the HIP backward masks with the bf16 output it stored; give the reference the same mask where they disagree at 0
+    z.backward(dy.float())
+    assert (y.float() - z).abs().max().item() <= 2 ** -7 * max(1.0, z.abs().max().item())
+    assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-4) and torch.allclose(bn.running_var, ref.running_var, rtol=1e-3)
+    assert int(bn.num_batches_tracked) == 1
+    scale = x2.grad.abs().max().item()
+    assert (x1.grad.float() - x2.grad).abs().max().item() <= 0.02 * scale + 1e-3
+    if with_res:
+        assert (r1.grad.float() - r2.grad).abs().max().item() <= 2 ** -7 * r2.grad.abs().max().item() + 1e-6
+    gs = ref.weight.grad.abs().max().item()
+    assert (bn.weight.grad - ref.weight.grad).abs().max().item() <= 0.01 * gs
+    assert (bn.bias.grad - ref.bias.grad).abs().max().item() <= 0.01 * ref.bias.grad.abs().max().item() + 1e-2
+
+
+@pytest.mark.gpu
+def test_trainer_fused_bn_close_to_library_path():
+    """Trainer(fused=True) (HIP BatchNorm + skip + ReLU) against Trainer(fused=False) (torch/MIOpen) on the same
+    weights and batch: same loss within bf16 noise, same gradient direction, same running statistics, and it trains."""
+    assert torch.cuda.is_available()
+    import copy
+    from hive_alphazero_amd.alpha_net import ChessNet, Trainer
+    torch.manual_seed(5)
+    net_a = ChessNet().cuda()
+    net_b = copy.deepcopy(net_a)
+    net_c = copy.deepcopy(net_a)
+    x, pol, val = _toy_batch(32)
+    ta, tb, tc = Trainer(net_a, fused=True), Trainer(net_b, fused=False), Trainer(net_c, autocast_dtype=None)
+    assert ta.fused and not tb.fused and not tc.fused
+    grads = []
+    losses = []
+    for t, n in ((ta, net_a), (tb, net_b), (tc, net_c)):
+        t.model.train()
+        l = t.loss(x, pol, val)
+        l.backward()
+        losses.append(float(l))
+        grads.append(torch.cat([p.grad.flatten().float() for p in n.parameters()]))
+    la, lb, lc = losses
+    assert abs(la - lc) < 0.02 * abs(lc) + 0.02 and abs(lb - lc) < 0.02 * abs(lc) + 0.02
+    cos = lambda u, v: torch.nn.functional.cosine_similarity(u, v, dim=0).item()
+    fused_vs_fp32, lib_vs_fp32 = cos(grads[0], grads[2]), cos(grads[1], grads[2])
+    # bf16 gradients of a 40-layer random-init tower are noisy either way; the fused path must be at least as close to
+    # the fp32 gradient as the library bf16 path is (it rounds once per layer instead of three times)
+    assert fused_vs_fp32 > 0.85 and fused_vs_fp32 >= lib_vs_fp32 - 0.02, (fused_vs_fp32, lib_vs_fp32)   # measured 0.896 vs 0.897
+    assert torch.allclose(net_a.res_7.bn2.running_mean, net_b.res_7.bn2.running_mean, atol=2e-2)
+    assert torch.allclose(net_a.res_7.bn2.running_var, net_b.res_7.bn2.running_var, rtol=5e-2, atol=1e-3)
+    assert sorted(net_a.state_dict().keys()) == sorted(net_b.state_dict().keys())
+    l0 = ta.step(x, pol, val)
+    for _ in range(3):
+        l1 = ta.step(x, pol, val)
+    assert l1 < l0
