@@ -63,23 +63,28 @@ __device__ __forceinline__ void reduce_rows(float (&a)[8], float (&b)[8], float 
     }
 }
 
-// Finish kernels run as one workgroup of 4 x 256 threads: thread (k, c) adds the partials of workgroups k, k+4, ...
-// for channel c; threads with k == 0 return true with the two totals.
-__device__ __forceinline__ bool sum_partials(const float *partial, int grid, float &a, float &b)
+// Finish kernels: 32 workgroups x 256 threads, workgroup w owns channels 8 w .. 8 w + 7; thread (k, j) adds the
+// partials of streaming workgroups k, k+32, ... for channel c = 8 w + j (16 independent loads per array); the threads
+// with k == 0 return true with the two totals of their channel.
+constexpr int kFinishGrid = kBnC / 8;
+__device__ __forceinline__ bool sum_partials(const float *partial, int grid, int &c, float &a, float &b)
 {
-    __shared__ float tot[4][2 * kBnC];
-    const int c = threadIdx.x & (kBnC - 1), k = threadIdx.x >> 8;
+    __shared__ float tot[32][16];
+    const int j = threadIdx.x & 7, k = threadIdx.x >> 3;
+    c = blockIdx.x * 8 + j;
     float s = 0.f, q = 0.f;
-    for (int g = k; g < grid; g += 4) {
+#pragma unroll 4
+    for (int g = k; g < grid; g += 32) {
         s += partial[(long long)g * 2 * kBnC + c];
         q += partial[(long long)g * 2 * kBnC + kBnC + c];
     }
-    tot[k][c] = s;
-    tot[k][kBnC + c] = q;
+    tot[k][j] = s;
+    tot[k][8 + j] = q;
     __syncthreads();
     if (k != 0) return false;
-    a = tot[0][c] + tot[1][c] + tot[2][c] + tot[3][c];
-    b = tot[0][kBnC + c] + tot[1][kBnC + c] + tot[2][kBnC + c] + tot[3][kBnC + c];
+    a = b = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) { a += tot[r][j]; b += tot[r][8 + j]; }
     return true;
 }
 
@@ -89,6 +94,7 @@ bn_fwd_stats_kernel(const __bf16 *__restrict__ x, long long rows, float *__restr
 {
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
     for (long long r = (long long)blockIdx.x * 8 + rl; r < rows; r += (long long)gridDim.x * 8) {
         float v[8];
         load8(x + r * kBnC + cg * 8, v);
@@ -99,15 +105,15 @@ bn_fwd_stats_kernel(const __bf16 *__restrict__ x, long long rows, float *__restr
 }
 
 // coef[0..255] = scale, [256..511] = shift
-__global__ void __launch_bounds__(4 * kBnC)
+__global__ void __launch_bounds__(kBnThreads)
 bn_fwd_finish_kernel(const float *__restrict__ partial, int grid, long long rows, const float *__restrict__ gamma,
                      const float *__restrict__ beta, float *__restrict__ running_mean, float *__restrict__ running_var,
                      float momentum, float eps, float *__restrict__ save_mean, float *__restrict__ save_invstd,
                      float *__restrict__ coef)
 {
     float s, q;
-    if (!sum_partials(partial, grid, s, q)) return;
-    const int c = threadIdx.x;
+    int c;
+    if (!sum_partials(partial, grid, c, s, q)) return;
     const float n = (float)rows;
     const float mean = s / n;
     const float var = fmaxf(q / n - mean * mean, 0.f);          // biased, as BatchNorm normalises with it
@@ -132,6 +138,7 @@ bn_fwd_apply_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ res
     float sc[8], sh[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { sc[i] = coef[cg * 8 + i]; sh[i] = coef[kBnC + cg * 8 + i]; }
+#pragma unroll 4
     for (long long r = (long long)blockIdx.x * 8 + rl; r < rows; r += (long long)gridDim.x * 8) {
         const long long o = r * kBnC + cg * 8;
         float v[8];
@@ -163,6 +170,7 @@ bn_bwd_stats_kernel(const __bf16 *__restrict__ dy, const __bf16 *__restrict__ y,
 #pragma unroll
     for (int i = 0; i < 8; ++i) { mu[i] = save_mean[cg * 8 + i]; is[i] = save_invstd[cg * 8 + i]; }
     float db[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
     for (long long r = (long long)blockIdx.x * 8 + rl; r < rows; r += (long long)gridDim.x * 8) {
         const long long o = r * kBnC + cg * 8;
         float g[8], xv[8];
@@ -181,14 +189,14 @@ bn_bwd_stats_kernel(const __bf16 *__restrict__ dy, const __bf16 *__restrict__ y,
 }
 
 // coef[0..255] = gamma/std, [256..511] = dbeta/N, [512..767] = dgamma/N
-__global__ void __launch_bounds__(4 * kBnC)
+__global__ void __launch_bounds__(kBnThreads)
 bn_bwd_finish_kernel(const float *__restrict__ partial, int grid, long long rows, const float *__restrict__ gamma,
                      const float *__restrict__ save_invstd, float *__restrict__ dgamma, float *__restrict__ dbeta,
                      float *__restrict__ coef)
 {
     float b, g;
-    if (!sum_partials(partial, grid, b, g)) return;
-    const int c = threadIdx.x;
+    int c;
+    if (!sum_partials(partial, grid, c, b, g)) return;
     dbeta[c] = b;
     dgamma[c] = g;
     const float n = (float)rows;
@@ -214,6 +222,7 @@ bn_bwd_apply_kernel(const __bf16 *__restrict__ dy, const __bf16 *__restrict__ y,
         cb[i] = coef[kBnC + cg * 8 + i];
         cgm[i] = coef[2 * kBnC + cg * 8 + i];
     }
+#pragma unroll 4
     for (long long r = (long long)blockIdx.x * 8 + rl; r < rows; r += (long long)gridDim.x * 8) {
         const long long o = r * kBnC + cg * 8;
         float g[8], xv[8];
@@ -260,7 +269,7 @@ extern "C" int hive_nn_bn_act_fwd(const void *x, const void *residual, const flo
     float *partial = workspace, *coef = workspace + (long long)kBnGrid * 2 * kBnC;
     const __bf16 *X = (const __bf16 *)x, *R = (const __bf16 *)residual;
     hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(grid), dim3(kBnThreads), 0, s, X, rows, partial);
-    hipLaunchKernelGGL(bn_fwd_finish_kernel, dim3(1), dim3(4 * kBnC), 0, s, partial, grid, rows, gamma, beta, running_mean,
+    hipLaunchKernelGGL(bn_fwd_finish_kernel, dim3(kFinishGrid), dim3(kBnThreads), 0, s, partial, grid, rows, gamma, beta, running_mean,
                        running_var, momentum, eps, save_mean, save_invstd, coef);
     if (R) hipLaunchKernelGGL((bn_fwd_apply_kernel<true>), dim3(grid), dim3(kBnThreads), 0, s, X, R, coef, rows, relu, (__bf16 *)y);
     else hipLaunchKernelGGL((bn_fwd_apply_kernel<false>), dim3(grid), dim3(kBnThreads), 0, s, X, R, coef, rows, relu, (__bf16 *)y);
@@ -282,7 +291,7 @@ extern "C" int hive_nn_bn_act_bwd(const void *dy, const void *x, const void *y, 
     const __bf16 *DY = (const __bf16 *)dy, *X = (const __bf16 *)x, *Y = (const __bf16 *)y;
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(grid), dim3(kBnThreads), 0, s, DY, Y, X, save_mean, save_invstd, rows, relu,
                        partial);
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(1), dim3(4 * kBnC), 0, s, partial, grid, rows, gamma, save_invstd, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(kFinishGrid), dim3(kBnThreads), 0, s, partial, grid, rows, gamma, save_invstd, dgamma,
                        dbeta, coef);
     if (dresidual)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), dim3(grid), dim3(kBnThreads), 0, s, DY, Y, X, save_mean, save_invstd,
