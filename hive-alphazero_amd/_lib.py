@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "hive_search_node_counts",
     # include/hive_nn.h
     "hive_nn_conv3x3", "hive_nn_resblock", "hive_nn_bn_workspace_floats", "hive_nn_bn_act_fwd", "hive_nn_bn_act_bwd",
+    "hive_nn_pack_conv3x3_weights",
 ]
 
 
@@ -105,6 +106,7 @@ def load():
     L.hive_nn_bn_workspace_floats.restype = i32
     L.hive_nn_bn_act_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i64, i32, i32, vp]
     L.hive_nn_bn_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
+    L.hive_nn_pack_conv3x3_weights.argtypes = [vp, i32, i32, i32, vp, vp]
     for name in ABI_SYMBOLS:
         getattr(L, name)
     _lib = L

@@ -189,6 +189,72 @@ class _BNAct(torch.autograd.Function):
         return dx, dgamma, dbeta, dres, None, None
 
 
+class _Conv3x3(torch.autograd.Function):
+    """3x3 convolution of the training step on the hand-written MFMA kernel: forward and data gradient are
+    hive_nn_conv3x3 (the data gradient = the same kernel on dy with transposed, 180-degree-rotated weights, packed by
+    hive_nn_pack_conv3x3_weights); the weight gradient stays on the library (MIOpen) path."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import _lib
+        L = _lib.load()
+        if x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        B, cin = x.shape[0], x.shape[1]
+        dev = x.device
+        cinp = (cin + 63) // 64 * 64
+        wp = torch.empty(9 * cinp * 256, dtype=torch.bfloat16, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        wsrc, wcl = _weight_layout(weight)
+        _lib.check(L.hive_nn_pack_conv3x3_weights(p(wsrc), cin, 0, wcl, p(wp), st))
+        b = bias if bias is not None else torch.zeros(256, dtype=torch.float32, device=dev)
+        y = torch.empty((B, 256, 12, 12), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+        _lib.check(L.hive_nn_conv3x3(p(x), cin, p(wp), p(b), None, p(y), B, 0, st))
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        L = _lib.load()
+        x, weight = ctx.saved_tensors
+        if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        B, cin = x.shape[0], x.shape[1]
+        dev = x.device
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty(9 * 256 * 256, dtype=torch.bfloat16, device=dev)
+            wsrc, wcl = _weight_layout(weight)
+            _lib.check(L.hive_nn_pack_conv3x3_weights(p(wsrc), cin, 1, wcl, p(wt), st))
+            dx = torch.empty_like(x)
+            zero = torch.zeros(256, dtype=torch.float32, device=dev)
+            _lib.check(L.hive_nn_conv3x3(p(dy), 256, p(wt), p(zero), None, p(dx), B, 0, st))
+        wb = weight.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dw = torch.ops.aten.convolution_backward(dy, x, wb, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                 (False, True, False))[1]
+        db = dy.float().sum(dim=(0, 2, 3)) if ctx.has_bias else None
+        return dx, dw.float(), db
+
+
+def _weight_layout(w):
+    """(tensor whose storage the pack kernel can index, channels_last flag) for an nn.Conv2d weight."""
+    if w.is_contiguous():
+        return w, 0
+    if w.is_contiguous(memory_format=torch.channels_last):
+        return w, 1
+    return w.contiguous(), 0
+
+
+def conv3x3(x, conv):
+    """conv(x) for a 3x3 / stride 1 / padding 1 nn.Conv2d with 256 output channels, through the HIP kernel."""
+    return _Conv3x3.apply(x, conv.weight, conv.bias)
+
+
 def bn_act(x, bn, residual=None, relu=True):
     """relu(bn(x) + residual) in training mode through the HIP kernels (updates bn's running statistics)."""
     return _BNAct.apply(x, bn.weight, bn.bias, residual, bn, relu)
@@ -199,19 +265,21 @@ class FusedTrainNet(nn.Module):
     state_dict see the reference's network), but every BatchNorm + skip + ReLU of the 256-channel tower is one fused
     HIP forward / backward (alpha_net.py:25-54); the two heads stay on the library path."""
 
-    def __init__(self, net):
+    def __init__(self, net, hip_conv=True):
         super().__init__()
         self.net = net
+        self.hip_conv = hip_conv
 
     def forward(self, s):
         net = self.net
         if not (net.training and s.is_cuda):      # eval mode (running statistics) and CPU runs use the modules as they are
             return net(s)
-        s = bn_act(net.conv.conv1(s), net.conv.bn1)
+        conv = conv3x3 if self.hip_conv else (lambda t, m: m(t))
+        s = bn_act(conv(s, net.conv.conv1), net.conv.bn1)
         for i in range(19):
             blk = getattr(net, "res_%i" % i)
-            out = bn_act(blk.conv1(s), blk.bn1)
-            s = bn_act(blk.conv2(out), blk.bn2, residual=s)
+            out = bn_act(conv(s, blk.conv1), blk.bn1)
+            s = bn_act(conv(out, blk.conv2), blk.bn2, residual=s)
         return net.outblock(s)
 
 

@@ -242,9 +242,53 @@ bn_bwd_apply_kernel(const __bf16 *__restrict__ dy, const __bf16 *__restrict__ y,
     }
 }
 
+// ---------------------------------------------------------------- weights of the training-step convolutions
+// fp32 [256][cin][3][3] (the nn.Conv2d parameter) -> bf16 fragment-major [9][cinp/32][16][4][16][8] of
+// hive_nn_conv3x3 (include/hive_nn.h), once per step and layer.  transpose != 0 builds the weights of the
+// data-gradient convolution instead: dx[q][ci] = sum_{tap,co} dy[q + tap][co] * w[co][ci][-tap], i.e. the same
+// kernel run on dy with input/output channels swapped and the taps rotated by 180 degrees.
+__global__ void __launch_bounds__(256)
+pack_weights_kernel(const float *__restrict__ w, int cin, int cinp, int transpose, int channels_last,
+                    __bf16 *__restrict__ out)
+{
+    const int ks_n = cinp / 32;
+    const int idx = blockIdx.x * 256 + threadIdx.x;              // one 8-channel vector of the output
+    if (idx >= 9 * ks_n * 16 * 4 * 16) return;
+    const int row = idx & 15, kg = (idx >> 4) & 3, mt = (idx >> 6) & 15, rest = idx >> 10;
+    const int ks = rest % ks_n, tap = rest / ks_n;
+    const int m = mt * 16 + row, c0 = ks * 32 + kg * 8;         // output channel of the GEMM, first of 8 reduction channels
+    const int wt = transpose ? 8 - tap : tap;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        float f = 0.f;
+        if (c < cin) {
+            const int ko = transpose ? c : m, ki = transpose ? m : c;      // indices into w[out channel][in channel][tap]
+            f = channels_last ? w[((long long)ko * 9 + wt) * cin + ki] : w[((long long)ko * cin + ki) * 9 + wt];
+        }
+        v[e] = (__bf16)f;
+    }
+    *reinterpret_cast<bf16x8 *>(out + (long long)idx * 8) = v;
+}
+
 }  // namespace hive
 
 using namespace hive;
+
+extern "C" int hive_nn_pack_conv3x3_weights(const float *w, int cin, int transpose, int channels_last, void *out,
+                                            void *stream)
+{
+    if (!w || !out || (cin != 56 && cin != 256) || (transpose && cin != 256))
+        return set_error(HIVE_E_ARG, "hive_nn_pack_conv3x3_weights: cin must be 56 or 256 (256 for the transposed form)");
+    const int cinp = (cin + 63) / 64 * 64;
+    const int vecs = 9 * (cinp / 32) * 16 * 4 * 16;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cin,
+                       cinp, transpose, channels_last, (__bf16 *)out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(HIVE_E_DEVICE, std::string("hive_nn_pack_conv3x3_weights: ") + hipGetErrorString(e));
+    return HIVE_OK;
+}
 
 #define BN_TRY(expr)                                                                                        \
     do {                                                                                                    \

@@ -49,6 +49,12 @@ int hive_nn_bn_act_bwd(const void *dy, const void *x, const void *y, const float
                        const float *save_invstd, void *dx, void *dresidual, float *dgamma, float *dbeta,
                        float *workspace, long long rows, int channels, int relu, void *stream);
 
+/* nn.Conv2d weight (f32, logical shape [256][cin][3][3]; channels_last = 0: stored in that order, 1: stored
+ * [256][3][3][cin] as torch.channels_last keeps it) -> the bf16 fragment-major layout hive_nn_conv3x3 reads (cin = 56
+ * or 256; out = bf16[9 * cinp * 256], cinp = cin rounded up to 64).  transpose != 0 (cin = 256 only) packs the weights
+ * of the data-gradient convolution: hive_nn_conv3x3(dy, 256, packed_T, ...) then returns dx of y = conv3x3(x, w). */
+int hive_nn_pack_conv3x3_weights(const float *w, int cin, int transpose, int channels_last, void *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

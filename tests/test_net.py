@@ -339,3 +339,41 @@ def test_trainer_fused_bn_close_to_library_path():
     for _ in range(3):
         l1 = ta.step(x, pol, val)
     assert l1 < l0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,weights_cl", [(256, False), (256, True), (56, True)])
+def test_hip_training_conv_matches_torch(cin, weights_cl):
+    """The training-step convolution (alpha_net._Conv3x3): forward and data gradient on hive_nn_conv3x3 (the data
+    gradient through the transposed / rotated weight packing), weight gradient on the library path -- against
+    F.conv2d autograd in fp32 on the same bf16-rounded operands.  Tolerance: bf16 output rounding (2^-8) on sums of
+    up to 2304 products accumulated in fp32."""
+    assert torch.cuda.is_available()
+    import torch.nn.functional as F
+    from hive_alphazero_amd.alpha_net import conv3x3
+    torch.manual_seed(11)
+    B = 8
+    conv = torch.nn.Conv2d(cin, 256, 3, padding=1, bias=(cin == 56)).cuda()
+    if weights_cl:
+        conv = conv.to(memory_format=torch.channels_last)                   # as Trainer keeps the network
+    with torch.no_grad():
+        conv.weight.copy_(conv.weight.to(torch.bfloat16).float())          # operands exactly representable in bf16
+    x = torch.randn((B, cin, 12, 12), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn((B, 256, 12, 12), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x1 = x.clone().requires_grad_(cin == 256)
+    y = conv3x3(x1, conv)
+    y.backward(dy)
+    gw, gb = conv.weight.grad.clone(), (conv.bias.grad.clone() if conv.bias is not None else None)
+    conv.weight.grad = None
+    if conv.bias is not None:
+        conv.bias.grad = None
+    x2 = x.float().requires_grad_(True)
+    z = F.conv2d(x2, conv.weight, conv.bias, padding=1)
+    z.backward(dy.float())
+    tol = lambda ref: 2 ** -7 * ref.abs().max().item()
+    assert (y.float() - z).abs().max().item() <= tol(z)
+    if cin == 256:
+        assert (x1.grad.float() - x2.grad).abs().max().item() <= tol(x2.grad)
+    assert (gw - conv.weight.grad).abs().max().item() <= 2 * tol(conv.weight.grad)
+    if gb is not None:
+        assert (gb - conv.bias.grad).abs().max().item() <= 1e-3 * conv.bias.grad.abs().max().item() + 1e-3
