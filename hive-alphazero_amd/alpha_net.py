@@ -189,6 +189,22 @@ class _BNAct(torch.autograd.Function):
         return dx, dgamma, dbeta, dres, None, None
 
 
+_CONST_CACHE = {}
+
+
+def _const(kind, cin, dev):
+    """Per-device constants of the training convolutions: a zero bias, and a bf16 weight-shaped tensor for the
+    library's weight-gradient call (it reads only the shape and memory format of that argument)."""
+    key = (kind, cin, dev)
+    if key not in _CONST_CACHE:
+        if kind == "zero_bias":
+            _CONST_CACHE[key] = torch.zeros(256, dtype=torch.float32, device=dev)
+        else:
+            _CONST_CACHE[key] = torch.zeros((256, cin, 3, 3), dtype=torch.bfloat16, device=dev).contiguous(
+                memory_format=torch.channels_last)
+    return _CONST_CACHE[key]
+
+
 class _Conv3x3(torch.autograd.Function):
     """3x3 convolution of the training step on the hand-written MFMA kernel: forward and data gradient are
     hive_nn_conv3x3 (the data gradient = the same kernel on dy with transposed, 180-degree-rotated weights, packed by
@@ -208,7 +224,7 @@ class _Conv3x3(torch.autograd.Function):
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         wsrc, wcl = _weight_layout(weight)
         _lib.check(L.hive_nn_pack_conv3x3_weights(p(wsrc), cin, 0, wcl, p(wp), st))
-        b = bias if bias is not None else torch.zeros(256, dtype=torch.float32, device=dev)
+        b = bias if bias is not None else _const("zero_bias", 0, dev)
         y = torch.empty((B, 256, 12, 12), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
         _lib.check(L.hive_nn_conv3x3(p(x), cin, p(wp), p(b), None, p(y), B, 0, st))
         ctx.save_for_backward(x, weight)
@@ -232,10 +248,8 @@ class _Conv3x3(torch.autograd.Function):
             wsrc, wcl = _weight_layout(weight)
             _lib.check(L.hive_nn_pack_conv3x3_weights(p(wsrc), cin, 1, wcl, p(wt), st))
             dx = torch.empty_like(x)
-            zero = torch.zeros(256, dtype=torch.float32, device=dev)
-            _lib.check(L.hive_nn_conv3x3(p(dy), 256, p(wt), p(zero), None, p(dx), B, 0, st))
-        wb = weight.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        dw = torch.ops.aten.convolution_backward(dy, x, wb, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+            _lib.check(L.hive_nn_conv3x3(p(dy), 256, p(wt), p(_const("zero_bias", 0, dev)), None, p(dx), B, 0, st))
+        dw = torch.ops.aten.convolution_backward(dy, x, _const("weight_like", cin, dev), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                  (False, True, False))[1]
         db = dy.float().sum(dim=(0, 2, 3)) if ctx.has_bias else None
         return dx, dw.float(), db
