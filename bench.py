@@ -126,6 +126,30 @@ def selfplay_measure(args, local_rank, world):
     return out
 
 
+def training_measure(steps, batch=512):
+    """Next-row side measurement: the reference's training step (alpha_net.py:117-162, batch 512) through
+    hive_alphazero_amd.alpha_net.Trainer -- bf16, hand-written BatchNorm / convolution kernels."""
+    import torch
+    from hive_alphazero_amd.alpha_net import ChessNet, Trainer
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = (torch.rand((batch, 56, 12, 12), device="cuda", generator=g) < 0.1).float()
+    pi = torch.softmax(torch.randn((batch, 1584), device="cuda", generator=g), 1)
+    z = torch.sign(torch.randn((batch,), device="cuda", generator=g))
+    torch.manual_seed(0)
+    tr = Trainer(ChessNet().cuda())
+    for _ in range(3):
+        tr.step(x, pi, z)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(x, pi, z)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    return {"workload": f"train_step_batch{batch}", "ms_per_step": round(el * 1e3, 2), "positions_per_s": round(batch / el, 1),
+            "TFLOPs_fwd_bwd_as_3x_fwd": round(3 * GFLOP_PER_LEAF * batch / el / 1e3, 1), "dtype": "bf16 (fp32 master weights)",
+            "fused_hip_kernels": bool(tr.fused), "loss": round(float(loss), 4)}
+
+
 def selfplay_cpu_baseline(sims, budget_s=10.0):
     """The reference's process model on ONE host core: sequential HivePlayer (hive_alphazero_amd.solo_play, pinned
     bit-exact to woker/solo_play.py) over the CPU oracle env, with a stub evaluator -- i.e. env + tree only, the
@@ -170,6 +194,7 @@ def main():
     ap.add_argument("--selfplay-plies", type=int, default=6, help="timed plies of the self-play side measurement (0 = skip)")
     ap.add_argument("--selfplay-warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline-selfplay", dest="cpu_baseline_selfplay", action="store_false")
+    ap.add_argument("--train-steps", type=int, default=10, help="timed steps of the training-step side measurement (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="skip the 4-stream overlapped side measurement (profiling runs: "
                     "concurrent launches stretch the per-kernel durations rocprof reports)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
@@ -326,6 +351,13 @@ def main():
             selfplay["games_per_min_all_gpus"] = round(float(t[0].item()), 2)
             selfplay["leaf_evals_per_s_all_gpus"] = round(float(t[1].item()), 1)
 
+    training = None
+    if rank == 0 and args.train_steps > 0:
+        try:
+            training = training_measure(args.train_steps)
+        except Exception as exc:                 # a side measurement never takes the headline line down
+            training = {"error": repr(exc)}
+
     t_side = time.perf_counter() - t_side0
     if rank == 0:
         launch_us = dev_ms * 1e3 / args.steps
@@ -355,13 +387,14 @@ def main():
             "saturated": sat,
             "host_buffers_pcie_inclusive": pcie,
             "selfplay": selfplay,
+            "training": training,
         }
         t_cpu0 = time.perf_counter()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(boards.cpu().numpy())
         # where the process's wall time goes (the timed region is only the K headline steps)
         out["wall_s"] = {"imports_and_corpus": round(t_setup, 2), "timed_region": round(wall_max, 4),
-                         "side_measurements_incl_selfplay_and_its_cpu_baseline": round(t_side, 2),
+                         "side_measurements_incl_selfplay_training_and_cpu_baselines": round(t_side, 2),
                          "movegen_cpu_baseline": round(time.perf_counter() - t_cpu0, 2)}
         print(json.dumps(out))
     if world > 1:
