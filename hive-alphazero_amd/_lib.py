@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     # include/hive_search.h
     "hive_search_create", "hive_search_destroy", "hive_search_set_stream", "hive_search_set_params",
     "hive_search_set_roots", "hive_search_select", "hive_search_backup", "hive_search_policy",
-    "hive_search_node_counts",
+    "hive_search_node_counts", "hive_search_set_transpositions", "hive_search_transposition_hits",
     # include/hive_nn.h
     "hive_nn_conv3x3", "hive_nn_resblock", "hive_nn_bn_workspace_floats", "hive_nn_bn_act_fwd", "hive_nn_bn_act_bwd",
     "hive_nn_pack_conv3x3_weights",
@@ -100,6 +100,8 @@ def load():
     L.hive_search_backup.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.hive_search_policy.argtypes = [vp, vp, vp, vp, i32]
     L.hive_search_node_counts.argtypes = [vp, vp]
+    L.hive_search_set_transpositions.argtypes = [vp, i32]
+    L.hive_search_transposition_hits.argtypes = [vp, vp]
     L.hive_nn_conv3x3.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp]
     L.hive_nn_resblock.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
     f32, i64 = ctypes.c_float, ctypes.c_longlong

@@ -15,7 +15,7 @@
 namespace hive {
 
 constexpr int EC = HIVE_EDGE_CAP;
-enum LeafKind : int8_t { LEAF_NONE = 0, LEAF_ROOT = 1, LEAF_EXPAND = 2, LEAF_TERMINAL = 3, LEAF_COLLISION = 4 };
+enum LeafKind : int8_t { LEAF_NONE = 0, LEAF_ROOT = 1, LEAF_EXPAND = 2, LEAF_TERMINAL = 3, LEAF_COLLISION = 4, LEAF_CAPDRAW = 5 };
 constexpr float kDrawSentinel = 5.0f;      // solo_play.py:180,183
 
 struct SearchDev {
@@ -38,6 +38,9 @@ struct SearchDev {
     int8_t *leaf_kind;                             // [L][G]
     int32_t *leaf_node;                            // [L][G]: terminal node reached / parent node of the expansion
     int32_t *leaf_edge;                            // [L][G]: parent edge of the expansion
+    int32_t *tt;                                   // [G][TT] open-addressing table position -> node (-1 empty)
+    int32_t *tt_hits;                              // [G] descents that continued through a transposition (statistics)
+    int TT, merge;                                 // table size (power of two), merging on/off
 };
 
 // ------------------------------------------------------------------ small device helpers
@@ -110,6 +113,50 @@ __device__ __forceinline__ void wave_copy(void *dst, const void *src, int bytes,
     for (int i = lane; i < bytes / 4; i += 64) d[i] = s[i];
 }
 
+// The reference keeps its tree in a dict keyed by GamePlay.state_key (solo_play.py:167-197, env_hive.py:70-94,151-168):
+// cells in board order with the piece keys bottom->top plus the side digit -- turn number and history excluded.
+// The same information is bytes 0..32 of the HiveBoard record (pos[22], 4-bit stack indices) and the turn parity.
+__device__ __forceinline__ uint32_t key_word(const uint32_t *rec, int i)      // i = 0..8
+{
+    uint32_t w = rec[i];
+    if (i == 8) w = (w & 0xFFu) | ((w >> 8) & 1u) << 8;       // lvl[10] and the parity of the turn byte
+    return w;
+}
+__device__ __forceinline__ uint32_t key_hash(const uint32_t *rec, int lane)
+{
+    unsigned long long h = 0ull;
+    if (lane < 9) h = splitmix(((unsigned long long)(lane + 1) << 32) | key_word(rec, lane));
+    for (int o = 8; o > 0; o >>= 1) h ^= __shfl_xor(h, o);      // lanes 0..15 hold the xor of lanes 0..8 (others add 0)
+    return (uint32_t)(__shfl(h, 0) >> 17);
+}
+__device__ __forceinline__ bool key_equal(const uint32_t *a, const uint32_t *b, int lane)
+{
+    bool ne = lane < 9 && key_word(a, lane) != key_word(b, lane);
+    return __ballot(ne) == 0ull;
+}
+// node holding the position `rec` of game g, or -1
+__device__ __forceinline__ int tt_find(const SearchDev &S, int g, const uint32_t *rec, int lane)
+{
+    const uint32_t mask = (uint32_t)S.TT - 1u;
+    uint32_t slot = key_hash(rec, lane) & mask;
+    for (int probe = 0; probe < S.TT; ++probe, slot = (slot + 1u) & mask) {
+        const int id = S.tt[(long long)g * S.TT + slot];
+        if (id < 0) return -1;
+        if (key_equal(rec, reinterpret_cast<const uint32_t *>(&S.node_board[(long long)g * S.MN + id]), lane)) return id;
+    }
+    return -1;
+}
+__device__ __forceinline__ void tt_insert(const SearchDev &S, int g, const uint32_t *rec, int id, int lane)
+{
+    const uint32_t mask = (uint32_t)S.TT - 1u;
+    uint32_t slot = key_hash(rec, lane) & mask;
+    for (int probe = 0; probe < S.TT; ++probe, slot = (slot + 1u) & mask)
+        if (S.tt[(long long)g * S.TT + slot] < 0) {
+            if (lane == 0) S.tt[(long long)g * S.TT + slot] = id;
+            return;
+        }
+}
+
 // ------------------------------------------------------------------ kernels
 __global__ void __launch_bounds__(256)
 search_reset_kernel(SearchDev S, const HiveBoard *__restrict__ boards, const HiveHistory *__restrict__ hist,
@@ -120,6 +167,7 @@ search_reset_kernel(SearchDev S, const HiveBoard *__restrict__ boards, const Hiv
     if (g >= S.G) return;
     wave_copy(&S.root_board[g], &boards[g], sizeof(HiveBoard), lane);
     wave_copy(&S.root_hist[g], &hist[g], sizeof(HiveHistory), lane);
+    for (int i = lane; i < S.TT; i += 64) S.tt[(long long)g * S.TT + i] = -1;
     if (lane == 0) {
         S.n_nodes[g] = 0;
         S.root_pending[g] = 0;
@@ -152,9 +200,19 @@ search_select_kernel(SearchDev S, int slot, unsigned long long sim, HiveBoard *_
     }
 
     const long long nbase = (long long)g * S.MN;
+    // The env of this simulation (deepcopy(env) of solo_play.py:158) lives in LDS and takes every move of the descent
+    // (env.move, solo_play.py:213): turn number and history planes are those of THIS path even when the nodes it runs
+    // through were first reached another way.
+    uint32_t *st = stage[threadIdx.x >> 6];
+    wave_copy(st, &S.node_board[nbase], sizeof(HiveBoard), lane);
+    wave_copy(st + 16, &S.node_hist[nbase], sizeof(HiveHistory), lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     int node = 0, depth = 0, kind = LEAF_NONE, leafnode = 0, leafedge = 0;
     while (true) {
-        if (S.node_term[nbase + node]) { kind = LEAF_TERMINAL; leafnode = node; break; }
+        if (S.node_term[nbase + node]) { kind = LEAF_TERMINAL; leafnode = node; break; }          // game over (solo_play.py:169-180)
+        if ((int)reinterpret_cast<const uint8_t *>(st)[33] >= S.prm.max_game_length) { kind = LEAF_CAPDRAW; break; }   // :181-183
         const int ne = S.node_nedge[nbase + node];
         const long long eb = (nbase + node) * EC;
         const float xx = sqrtf((float)S.node_sum_n[nbase + node] + 1.0f);
@@ -197,29 +255,29 @@ search_select_kernel(SearchDev S, int slot, unsigned long long sim, HiveBoard *_
             S.e_w[eb + bidx] -= 1.0f;
             pnode[depth] = node;
             pedge[depth] = bidx;
-            if (child == -1) S.e_child[eb + bidx] = -2;     // expansion in flight
+            apply_action(reinterpret_cast<HiveBoard *>(st), reinterpret_cast<HiveHistory *>(st + 16), S.e_act[eb + bidx]);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         depth++;
-        if (child == -1) { kind = LEAF_EXPAND; leafnode = node; leafedge = bidx; break; }
+        if (child == -1 && S.merge) {
+            // `state in self.tree` (solo_play.py:188): the position may already have a node, reached by another move order
+            const int known = tt_find(S, g, st, lane);
+            if (known >= 0) {
+                child = known;
+                if (lane == 0) { S.e_child[eb + bidx] = known; S.tt_hits[g] += 1; }
+            }
+        }
+        if (child == -1) {
+            if (lane == 0) S.e_child[eb + bidx] = -2;                 // expansion in flight
+            kind = LEAF_EXPAND; leafnode = node; leafedge = bidx;
+            break;
+        }
         if (child == -2 || depth >= S.MN - 1) { kind = LEAF_COLLISION; break; }
         node = child;
     }
     if (kind == LEAF_EXPAND) {
-        // child position = parent position + action (deepcopy(env) + env.move, solo_play.py:158,213):
-        // staged in LDS so that one lane can run the byte-level move logic on it
-        uint32_t *st = stage[threadIdx.x >> 6];
-        wave_copy(st, &S.node_board[nbase + leafnode], sizeof(HiveBoard), lane);
-        wave_copy(st + 16, &S.node_hist[nbase + leafnode], sizeof(HiveHistory), lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (lane == 0) {
-            int a = S.e_act[(nbase + leafnode) * EC + leafedge];
-            apply_action(reinterpret_cast<HiveBoard *>(st), reinterpret_cast<HiveHistory *>(st + 16), a);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         wave_copy(&leaf_boards[g], st, sizeof(HiveBoard), lane);
         wave_copy(&leaf_hist[g], st + 16, sizeof(HiveHistory), lane);
     }
@@ -261,12 +319,25 @@ search_backup_kernel(SearchDev S, int slot, const HiveBoard *__restrict__ leaf_b
     }
 
     float ret;
+    int known = -1;
+    const bool capped = kind == LEAF_CAPDRAW ||
+                        (kind == LEAF_EXPAND && !over[g] && (int)leaf_boards[g].turn >= S.prm.max_game_length);
+    if (kind == LEAF_EXPAND && !capped && S.merge)          // another in-flight slot may have created this position meanwhile
+        known = tt_find(S, g, reinterpret_cast<const uint32_t *>(&leaf_boards[g]), lane);
     if (kind == LEAF_TERMINAL) {
         ret = S.node_tv[nbase + S.leaf_node[sg]];
+    } else if (capped) {
+        // length cap (solo_play.py:181-183): a property of this path's turn count, not of the position -- no node
+        if (kind == LEAF_EXPAND && lane == 0) S.e_child[(nbase + S.leaf_node[sg]) * EC + S.leaf_edge[sg]] = -1;
+        ret = kDrawSentinel;
+    } else if (known >= 0) {
+        if (lane == 0) S.e_child[(nbase + S.leaf_node[sg]) * EC + S.leaf_edge[sg]] = known;
+        ret = S.node_term[nbase + known] ? S.node_tv[nbase + known] : v[g];
     } else {
         const int id = (kind == LEAF_ROOT) ? 0 : S.n_nodes[g];
         wave_copy(&S.node_board[nbase + id], &leaf_boards[g], sizeof(HiveBoard), lane);
         wave_copy(&S.node_hist[nbase + id], &leaf_hist[g], sizeof(HiveHistory), lane);
+        if (S.merge) tt_insert(S, g, reinterpret_cast<const uint32_t *>(&leaf_boards[g]), id, lane);
         const unsigned turn = leaf_boards[g].turn;
         const int stm = (turn & 1u) ? 0 : 1;
         bool term = false;
@@ -484,6 +555,13 @@ static int search_alloc(HiveSearch *s, int games, int max_nodes, int slots)
     S_TRY(alloc(s, &d.leaf_kind, LG));
     S_TRY(alloc(s, &d.leaf_node, LG));
     S_TRY(alloc(s, &d.leaf_edge, LG));
+    d.TT = 64;
+    while (d.TT < 2 * max_nodes) d.TT *= 2;
+    d.merge = 1;
+    S_TRY(alloc(s, &d.tt, (size_t)games * d.TT));
+    S_TRY(alloc(s, &d.tt_hits, (size_t)games));
+    S_TRY(hipMemset(d.tt, 0xFF, sizeof(int32_t) * (size_t)games * d.TT));
+    S_TRY(hipMemset(d.tt_hits, 0, sizeof(int32_t) * games));
     S_TRY(hipMemset(d.n_nodes, 0, sizeof(int32_t) * games));
     S_TRY(hipMemset(d.active, 0, games));
     S_TRY(hipMemset(d.root_pending, 0, games));
@@ -582,6 +660,21 @@ int hive_search_policy(HiveSearch *s, float *policy, int32_t *action, int32_t *s
     hipLaunchKernelGGL(search_policy_kernel, wave_grid(s->d.G), dim3(256), 0, s->stream, s->d, s->sim++, policy, action, sum_n,
                        selfplay);
     S_TRY(hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_search_set_transpositions(HiveSearch *s, int merge)
+{
+    if (!s) return hive::set_error(HIVE_E_ARG, "null handle");
+    s->d.merge = merge ? 1 : 0;
+    return HIVE_OK;
+}
+
+int hive_search_transposition_hits(HiveSearch *s, int32_t *hits)
+{
+    if (!s || !hits) return hive::set_error(HIVE_E_ARG, "null argument");
+    S_TRY(hipSetDevice(s->device));
+    S_TRY(hipMemcpyAsync(hits, s->d.tt_hits, sizeof(int32_t) * s->d.G, hipMemcpyDeviceToDevice, s->stream));
     return HIVE_OK;
 }
 

@@ -31,7 +31,7 @@ class TreeSearch:
     evaluator(planes[B,12,12,56]) -> (p fp32 [B,1584] softmax, v fp32 [B])."""
 
     def __init__(self, games, sims, evaluator, device=None, slots=1, seed=0, plane_dtype=torch.bfloat16,
-                 c_puct=0.7, noise_eps=0.25, dirichlet_alpha=0.3, max_nodes=None):
+                 c_puct=0.7, noise_eps=0.25, dirichlet_alpha=0.3, max_nodes=None, transpositions=True):
         L = load()
         if L.hive_device_count() <= 0 or not torch.cuda.is_available():
             raise _lib.HiveError(-2, "no HIP device visible: hive_alphazero_amd has no CPU path")
@@ -43,6 +43,8 @@ class TreeSearch:
         check(L.hive_search_create(games, self.max_nodes, slots, self.device.index, seed, ctypes.byref(self._h)))
         prm = _Params(c_puct, noise_eps, dirichlet_alpha, MAX_GAME_LENGTH)
         check(L.hive_search_set_params(self._h, ctypes.byref(prm)))
+        # the reference's tree is a dict keyed by state_key: positions reached by two move orders share one entry
+        check(L.hive_search_set_transpositions(self._h, 1 if transpositions else 0))
         n = games * slots
         dev = self.device
         self.plane_dtype = plane_dtype
@@ -109,6 +111,13 @@ class TreeSearch:
         out = torch.zeros((self.games,), dtype=torch.int32, device=self.device)
         self._stream()
         check(self.L.hive_search_node_counts(self._h, _p(out)))
+        return out
+
+    def transposition_hits(self):
+        """int32[games]: descents that continued through a node first reached by another move order."""
+        out = torch.zeros((self.games,), dtype=torch.int32, device=self.device)
+        self._stream()
+        check(self.L.hive_search_transposition_hits(self._h, _p(out)))
         return out
 
 

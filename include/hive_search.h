@@ -15,9 +15,9 @@
  *   hive_search_backup   expansion (priors masked + renormalised, solo_play.py:304-313) and the
  *                        value backup with the reference's draw sentinel (solo_play.py:217-247)
  *
- * Differences from the reference, by design: a plain tree per game instead
- * of a dict keyed by state_key (no transposition merging); fp32 statistics; the Dirichlet noise
- * comes from a counter-based generator, not numpy's stream.  The reference-exact sequential
+ * Differences from the reference, by design: an explicit node pool per game instead of a
+ * dict keyed by state_key (transpositions are merged through a hash table, see below); fp32 statistics; the
+ * Dirichlet noise comes from a counter-based generator, not numpy's stream.  The reference-exact sequential
  * search is hive-alphazero_amd/solo_play.py.
  *
  * All pointers are DEVICE pointers; the caller allocates leaf/policy buffers, the handle owns the
@@ -70,6 +70,14 @@ int hive_search_backup(HiveSearch *s, int slot, const HiveBoard *leaf_boards, co
  * sum_n = int32[games] (may be NULL).  selfplay != 0 adds self_play.py:139-157: for turn <= 6 the
  * move is resampled from (1 - e) * policy + e * Dirichlet(0.5) over the legal moves, e = 0.7 - 0.15 * int(turn+1)/2. */
 int hive_search_policy(HiveSearch *s, float *policy, int32_t *action, int32_t *sum_n, int selfplay);
+
+/* The reference's tree is a dict keyed by GamePlay.state_key (solo_play.py:167-197; the key holds the pieces of every
+ * cell bottom->top and the side to move, not the turn number or the history): a position reached by two move orders is
+ * ONE entry with shared statistics.  merge != 0 (the default) gives the GPU tree the same semantics through a per-game
+ * hash table over bytes 0..32 + turn parity of the HiveBoard record; merge == 0 keeps a plain tree.
+ * hive_search_transposition_hits: int32[games], descents that continued through such a shared node since create. */
+int hive_search_set_transpositions(HiveSearch *s, int merge);
+int hive_search_transposition_hits(HiveSearch *s, int32_t *hits);
 
 /* Statistics for tests: nodes allocated per tree (int32[games]). */
 int hive_search_node_counts(HiveSearch *s, int32_t *counts);

@@ -84,6 +84,50 @@ def test_search_matches_sequential_reference_without_noise(prefix_seed, plies):
     ts.close(); B.close()
 
 
+@pytest.mark.parametrize("prefix_seed,plies", [(44, 24), (45, 32), (52, 24), (55, 48)])
+def test_search_merges_transpositions_like_the_reference_dict(prefix_seed, plies):
+    """The reference's tree is a dict keyed by state_key (solo_play.py:167-197): two move orders into one position
+    share ONE entry.  At 600 simulations from these positions that happens 6-10 times; the GPU search (hash-table
+    merging, the simulation's env carried along the path) must return the policy, visit total and move of the
+    sequential HivePlayer, and the plain-tree mode must be what deviates."""
+    assert torch.cuda.is_available()
+    import hive_alphazero_amd.solo_play as sp
+    from hive_alphazero_amd import batch, mcts
+    from hive_alphazero_amd.env_hive import GamePlay
+    sims = 600
+    rng = np.random.default_rng(prefix_seed)
+    g = GamePlay(1050, 900)
+    for _ in range(plies):
+        acts = g.actions()
+        g.move(int(acts[rng.integers(len(acts))]))
+    sp.SEARCH_THREADS = 1
+    old_eps = sp.noise_eps
+    sp.noise_eps = 0.0
+    try:
+        player = sp.HivePlayer(pipes=[StubPipe()])
+        player.simulation_num_per_move = sims
+        np.random.seed(0)
+        move, (ref_policy, ref_visits) = player.action(g)       # visit distribution, or the priors when every W < 0
+        ref_policy = np.asarray(ref_policy, dtype=np.float64)
+    finally:
+        sp.noise_eps = old_eps
+    B = batch.BoardBatch(1)
+    B.import_state(g._rec.reshape(1, 64), g._hist.reshape(1, 384))
+    rb, rh = B.export_state()
+    out = {}
+    for merge in (True, False):
+        ts = mcts.TreeSearch(1, sims, _host_stub_evaluator, plane_dtype=torch.float32, noise_eps=0.0, transpositions=merge)
+        action, policy, sum_n = ts.search(rb, rh)
+        out[merge] = (float(np.abs(policy[0].cpu().numpy().astype(np.float64) - ref_policy).max()), int(action[0].item()),
+                      int(sum_n[0].item()), int(ts.transposition_hits()[0].item()))
+        ts.close()
+    B.close()
+    diff, act, n, hits = out[True]
+    assert hits >= 4                                       # the case really exercises shared entries
+    assert diff < 1e-6 and act == move and n == int(ref_visits) >= sims - 1      # lines that return to the root position add root visits
+    assert out[False][3] == 0 and out[False][0] > 1e-3     # without merging the same search comes out differently
+
+
 def test_selfplay_engine_runs_and_stays_legal():
     assert torch.cuda.is_available()
     from hive_alphazero_amd import mcts
