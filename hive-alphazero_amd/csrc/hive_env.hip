@@ -417,15 +417,14 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
 #endif
 
     // ---------------- phase 0: stage records, clear accumulators
-    for (int i = tid; i < G * 4; i += nthreads) {
-        int b = i >> 2, part = i & 3;
-        uint4 v;
-        if (gbase + b < n) v = reinterpret_cast<const uint4 *>(boards)[(gbase + b) * 4 + part];
-        else if (part == 0) v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        else if (part == 1) v = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, 0u);
-        else if (part == 2) v = make_uint4(0x00010100u, 0u, 0u, 0u);
-        else v = make_uint4(0u, 0u, 0u, 0u);
-        reinterpret_cast<uint4 *>(sm.state[b])[part] = v;
+    // the record load is issued first and lands while the accumulators are being cleared (G * 4 <= 64: one trip)
+    uint4 rec_part = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < G * 4) {
+        const int b = tid >> 2, part = tid & 3;
+        if (gbase + b < n) rec_part = reinterpret_cast<const uint4 *>(boards)[(gbase + b) * 4 + part];
+        else if (part == 0) rec_part = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        else if (part == 1) rec_part = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, 0u);
+        else if (part == 2) rec_part = make_uint4(0x00010100u, 0u, 0u, 0u);
     }
     for (int i = tid; i < G * 6; i += nthreads) {
         (&sm.occ[0][0])[i] = 0u;
@@ -438,6 +437,7 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         reinterpret_cast<uint4 *>(&sm.cellmask[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) { sm.done = 0; sm.pin_done = 0; sm.adj_done = 0; }
     if (tid < G) { sm.nlegal[tid] = 0; sm.pinmask[tid] = 0u; }
+    if (tid < G * 4) reinterpret_cast<uint4 *>(sm.state[tid >> 2])[tid & 3] = rec_part;
     __syncthreads();
 
     // occupancy and top-colour boards: every (board, piece) pair ORs its bit in
@@ -448,8 +448,15 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         if (c < (unsigned)kCells) {
             unsigned lb = state_byte(st, 22u + ((unsigned)q >> 1));
             unsigned lv = (q & 1) ? (lb >> 4) : (lb & 15u);
+            // stack height = pieces standing on cell c: four position bytes per step (exact zero-byte test of w ^ cccc)
             unsigned h = 0;
-            HIVE_UNROLL for (int r = 0; r < 22; ++r) h += (state_byte(st, (unsigned)r) == c) ? 1u : 0u;
+            const uint32_t cccc = c * 0x01010101u;
+            HIVE_UNROLL for (int wq = 0; wq < 6; ++wq) {
+                uint32_t x = st[wq] ^ cccc;
+                if (wq == 5) x |= 0xFFFF0000u;                       // bytes 22, 23 are stack indices, not positions
+                const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);      // 0x80 where the byte was 0
+                h += (unsigned)__popc(z);
+            }
             unsigned wi, bit;
             cell_word_bit(c, wi, bit);
             atomicOr(&sm.occ[b][wi], 1u << bit);
