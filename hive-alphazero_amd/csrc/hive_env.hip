@@ -84,6 +84,7 @@ struct alignas(16) Smem {
     alignas(16) uint32_t cellmask[G][kCells];   // bit q: piece q stands on this cell
     alignas(16) uint32_t adj[G][24];       // piece graph: bit j of row q = pieces q and j share a cell or touch
     uint32_t pinmask[G];         // bit q: lifting piece q would split the hive (or it is the only piece)
+    alignas(8) uint32_t place[G][6];   // where the side to move may place a piece from its hand (before the turn gate)
     int pin_done;                // pin waves that have published their pinmask bits
     int adj_done;                // pin waves that have written their share of the adjacency rows
     unsigned long long feat[FULL ? G : 1][FULL ? kCells : 1];   // 56 feature bits per cell
@@ -119,7 +120,7 @@ struct PieceInfo {
 template <int ANT_STEPS>
 __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint32_t *occ_p, const uint32_t *topw_p,
                                                  const uint8_t *pinfo, const uint32_t *pinmask_p, const int *pin_done_p,
-                                                 int q, int type, bool own, bool valid)
+                                                 const uint32_t *place_p, int q, int type, bool own, bool valid)
 {
     PieceInfo out;
     const unsigned turn = state_byte(st, 33);
@@ -261,17 +262,8 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
             bool first = true;      // every earlier slot of the same type is already on the board
             if (slot > g0) first = state_byte(st, (unsigned)(color * 11 + g0)) < (unsigned)kCells;
             if (slot > g0 + 1) first = first && state_byte(st, (unsigned)(color * 11 + g0 + 1)) < (unsigned)kCells;
-            if (first) {
-                BB base = bb_andn(nmt, occ);
-                if (turn == 1u) D = bb_and(base, bb_bit((unsigned)kStartCell));
-                else if (turn == 2u) D = bb_and(base, nocc);
-                else if (gate) {
-                    // placement_is_allowed (move_checker.py:168-179): no neighbour topped by the other colour
-                    BB topw = bb_load(topw_p);
-                    BB top_enemy = color == 0 ? bb_andn(occ, topw) : topw;
-                    D = bb_andn(bb_and(base, nocc), bb_neighbours(top_enemy));
-                }
-            }
+            // the destinations are the same for every piece in the mover's hand: placement_board() built them once
+            if (first && (turn <= 2u || gate)) D = bb_load(place_p);
         }
     } else if (movable) {
         const bool adjacent_domain = (type == T_QUEEN || type == T_BEETLE);
@@ -295,6 +287,29 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     out.on_top = on_top;
     out.pinned = pinned;
     return out;
+}
+
+// Where the side to move may put a piece from its hand (env_hive.py:218-232 with move_checker.py:9-55,168-179), one
+// quad per board: turn 1 the start tile, turn 2 any empty tile of next_move_tiles next to the hive (colour rule waived),
+// later empty hive-adjacent tiles none of whose neighbours is topped by the other colour.  The turn gate (queen rules)
+// is per piece type and applied by the reader.
+__device__ __forceinline__ BB placement_board(const uint32_t *st, const uint32_t *occ_p, const uint32_t *topw_p)
+{
+    const unsigned turn = state_byte(st, 33);
+    const unsigned mode = state_byte(st, 34) & 3u;
+    const int stm = (turn & 1u) ? 0 : 1;
+    const BB occ = bb_load(occ_p);
+    const BB nocc = bb_neighbours(occ);
+    const BB empty_adj = bb_andn(nocc, occ);
+    BB nmt = empty_adj;
+    if (mode == 1u) nmt = bb_bit((unsigned)kStartCell);
+    else if (mode == 2u) nmt = bb_and(empty_adj, bb_bit((unsigned)kTurn2Cell));
+    const BB base = bb_andn(nmt, occ);
+    if (turn == 1u) return bb_and(base, bb_bit((unsigned)kStartCell));
+    if (turn == 2u) return bb_and(base, nocc);
+    const BB topw = bb_load(topw_p);
+    const BB top_enemy = stm == 0 ? bb_andn(occ, topw) : topw;
+    return bb_andn(bb_and(base, nocc), bb_neighbours(top_enemy));
 }
 
 // ------------------------------------------------------------------ one-hive test on the piece graph
@@ -474,6 +489,8 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     const unsigned turn = state_byte(st, 33);
     const int stm = (turn & 1u) ? 0 : 1;
     const int type = slot_type(wv);
+    if (wave_id == kPinWaves - 1)        // published together with this wave's pin results (pin_done)
+        bb_store(sm.place[bl], placement_board(sm.state[bl], sm.occ[bl], sm.topw[bl]));
     if (wave_id < kPinWaves) {
         // the three lightest waves (Queen, Beetles) settle the one-hive question for the whole workgroup first
         pin_phase<FULL>(sm, wave_id, lane);
@@ -483,7 +500,7 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     bool own;
     if (!FULL) { q = stm * 11 + wv; own = true; }
     else { int col = item >> 3; q = col * 11 + wv; own = (col == stm); }
-    PieceInfo pc = piece_dests<HIVE_ANT_STEPS>(st, sm.occ[bl], sm.topw[bl], sm.pinfo[bl], &sm.pinmask[bl], &sm.pin_done, q,
+    PieceInfo pc = piece_dests<HIVE_ANT_STEPS>(st, sm.occ[bl], sm.topw[bl], sm.pinfo[bl], &sm.pinmask[bl], &sm.pin_done, sm.place[bl], q,
                                                            type, own, valid);
     HIVE_STAMP(1);
     if (own && (mask != nullptr || count != nullptr)) {
