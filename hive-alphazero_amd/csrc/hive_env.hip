@@ -84,7 +84,8 @@ struct alignas(16) Smem {
     alignas(16) uint32_t cellmask[G][kCells];   // bit q: piece q stands on this cell
     alignas(16) uint32_t adj[G][24];       // piece graph: bit j of row q = pieces q and j share a cell or touch
     uint32_t pinmask[G];         // bit q: lifting piece q would split the hive (or it is the only piece)
-    alignas(8) uint32_t place[G][6];   // where the side to move may place a piece from its hand (before the turn gate)
+    alignas(8) uint32_t place[G][12];  // per board: [0..5] where the side to move may place a piece from its hand (before the
+                                       // turn gate), [6..11] next_move_tiles
     int pin_done;                // pin waves that have published their pinmask bits
     int adj_done;                // pin waves that have written their share of the adjacency rows
     unsigned long long feat[FULL ? G : 1][FULL ? kCells : 1];   // 56 feature bits per cell
@@ -124,7 +125,6 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
 {
     PieceInfo out;
     const unsigned turn = state_byte(st, 33);
-    const unsigned mode = state_byte(st, 34) & 3u;
     const int stm = (turn & 1u) ? 0 : 1;
     const int color = q >= 11 ? 1 : 0, slot = q - 11 * color;
     const unsigned c = state_byte(st, (unsigned)q);
@@ -147,7 +147,6 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     const BB srcbit = bb_bit(on_board ? c : 255u);
     const BB occp = (on_board && !stacked) ? bb_xor(occ, srcbit) : occ;
     const BB nsrc = on_board ? bb_load(d_tables.nmask[c]) : bb_zero();      // the six neighbours of src
-    BB nocc;                                                                // neighbours(occ)
 
     // The one-hive test (move_checker.py:58-83 / env_hive.py:509-530) is not made here: the pin waves
     // (pin_phase below) decide it for every piece of the workgroup on the 22-node piece graph while
@@ -172,13 +171,11 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 V = nx;
             }
         }
-        nocc = bb_neighbours(occ);
         rule = bb_andn(bb_and(bb_andn(bb_neighbours(V), occ), L), nsrc);
     } else {
         BB S[6];
         occupancy_views(occp, S);
         SlideCtx ctx = make_slide_ctx(occp, S);
-        nocc = bb_or(ctx.nocc, nsrc);            // N(occ) = N(occ without the mover) | N(mover)
         if (type == T_QUEEN) {
             rule = slide_step(ctx, srcbit);                       // pieces.py:35-44
         } else if (type == T_ANT) {
@@ -243,11 +240,6 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     const bool pinned = ((*pinmask_p >> q) & 1u) != 0u;
     const bool movable = on_top && !pinned;
 
-    // ---- next_move_tiles (env_hive.py:66-69,150-161)
-    const BB empty_adj = bb_andn(nocc, occ);
-    BB nmt = empty_adj;
-    if (mode == 1u) nmt = bb_bit((unsigned)kStartCell);
-    else if (mode == 2u) nmt = bb_and(empty_adj, bb_bit((unsigned)kTurn2Cell));
 
     // ---- turn gating (move_checker.py:38-55)
     bool gate = true;
@@ -270,11 +262,11 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
         BB domain;
         if (!own) domain = bb_full();
         else if (adjacent_domain) domain = nsrc;
-        else domain = nmt;
+        else domain = bb_load(place_p + 6);       // next_move_tiles (env_hive.py:66-69,150-161), shared per board
         if (turn <= 2u) {
             BB base = bb_andn(type == T_BEETLE ? bb_full() : bb_not(occ), srcbit);
             D = bb_and(domain, base);
-            D = bb_and(D, turn == 1u ? bb_bit((unsigned)kStartCell) : nocc);
+            D = bb_and(D, turn == 1u ? bb_bit((unsigned)kStartCell) : bb_neighbours(occ));
         } else if (gate) {
             D = bb_and(rule, domain);
         }
@@ -293,7 +285,7 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
 // quad per board: turn 1 the start tile, turn 2 any empty tile of next_move_tiles next to the hive (colour rule waived),
 // later empty hive-adjacent tiles none of whose neighbours is topped by the other colour.  The turn gate (queen rules)
 // is per piece type and applied by the reader.
-__device__ __forceinline__ BB placement_board(const uint32_t *st, const uint32_t *occ_p, const uint32_t *topw_p)
+__device__ __forceinline__ BB placement_board(const uint32_t *st, const uint32_t *occ_p, const uint32_t *topw_p, BB &nmt)
 {
     const unsigned turn = state_byte(st, 33);
     const unsigned mode = state_byte(st, 34) & 3u;
@@ -301,7 +293,7 @@ __device__ __forceinline__ BB placement_board(const uint32_t *st, const uint32_t
     const BB occ = bb_load(occ_p);
     const BB nocc = bb_neighbours(occ);
     const BB empty_adj = bb_andn(nocc, occ);
-    BB nmt = empty_adj;
+    nmt = empty_adj;                            // next_move_tiles (env_hive.py:66-69,150-161)
     if (mode == 1u) nmt = bb_bit((unsigned)kStartCell);
     else if (mode == 2u) nmt = bb_and(empty_adj, bb_bit((unsigned)kTurn2Cell));
     const BB base = bb_andn(nmt, occ);
@@ -489,8 +481,12 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     const unsigned turn = state_byte(st, 33);
     const int stm = (turn & 1u) ? 0 : 1;
     const int type = slot_type(wv);
-    if (wave_id == kPinWaves - 1)        // published together with this wave's pin results (pin_done)
-        bb_store(sm.place[bl], placement_board(sm.state[bl], sm.occ[bl], sm.topw[bl]));
+    if (wave_id == kPinWaves - 1) {      // published together with this wave's pin results (pin_done)
+        BB nmt;
+        const BB pl = placement_board(sm.state[bl], sm.occ[bl], sm.topw[bl], nmt);
+        bb_store(sm.place[bl], pl);
+        bb_store(sm.place[bl] + 6, nmt);
+    }
     if (wave_id < kPinWaves) {
         // the three lightest waves (Queen, Beetles) settle the one-hive question for the whole workgroup first
         pin_phase<FULL>(sm, wave_id, lane);
