@@ -366,11 +366,14 @@ __device__ __forceinline__ void pin_phase(Smem<FULL> &sm, int wave, int lane)
         ++pin_trips;
 #endif
         if (act) {
-            uint32_t nx = reach;
-            HIVE_UNROLL for (int i = 0; i < 22; ++i) nx |= a[i] & (uint32_t)(((int)(nx << (31 - i))) >> 31);
+            uint32_t up = reach;
+            HIVE_UNROLL for (int i = 0; i < 22; ++i) up |= a[i] & (uint32_t)(((int)(up << (31 - i))) >> 31);
+            uint32_t nx = up;
             HIVE_UNROLL for (int i = 21; i >= 0; --i) nx |= a[i] & (uint32_t)(((int)(nx << (31 - i))) >> 31);
             const bool covered = (target & ~nx) == 0u;
-            const bool fixed = nx == reach;
+            // a descending sweep that adds nothing has looked at every reached piece and found all its neighbours
+            // reached: the set is closed (no need for another round trip to see that nothing grows)
+            const bool fixed = nx == up;
             reach = nx;
             if (covered) act = false;
             else if (fixed) { act = false; pinned = true; }
