@@ -167,7 +167,7 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
             if (ga) {
                 BB n1 = bb_or(V, bb_and(bb_neighbours(V), Lo));
                 BB nx = bb_or(n1, bb_and(bb_neighbours(n1), Lo));
-                if (bb_eq(nx, V)) ga = false;
+                if (bb_eq(nx, n1)) ga = false;              // the last expansion added nothing: closed
                 V = nx;
             }
         }
@@ -184,9 +184,12 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
             while (__any(aa)) {
                 HIVE_COUNT_ITER();
                 if (aa) {
-                    BB nx = R;
-                    HIVE_UNROLL for (int u = 0; u < ANT_STEPS; ++u) nx = bb_or(nx, slide_step(ctx, nx));
-                    if (bb_eq(nx, R)) aa = false;
+                    BB nx = R, before_last = R;
+                    HIVE_UNROLL for (int u = 0; u < ANT_STEPS; ++u) {
+                        before_last = nx;
+                        nx = bb_or(nx, slide_step(ctx, nx));
+                    }
+                    if (bb_eq(nx, before_last)) aa = false;     // the last expansion added nothing: closed
                     R = nx;
                 }
             }
