@@ -24,9 +24,9 @@ HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md "HB
 # HBM bytes per board from the PMC passes in profiles/r01_movegen_pmc_traffic.md: (2 x FETCH_SIZE + WRITE_SIZE) KiB
 # per 4096-board launch = 1,614,848 B (gfx950 FETCH_SIZE correction applied); not measurable from inside bench.py
 MOVEGEN_TRAFFIC_BYTES_PER_BOARD = 394
-# the bound that actually binds: 512 VALU wave-instructions per board (PMC, profiles/r01_movegen_pmc_valu.md), each
+# the bound that actually binds: 489 VALU wave-instructions per board (PMC, profiles/r01_movegen_pmc_valu.md), each
 # occupying one of the 1024 SIMDs for 4 cycles at 2.4 GHz
-MOVEGEN_VALU_PER_BOARD = 512
+MOVEGEN_VALU_PER_BOARD = 489
 VALU_ISSUE_PEAK_MBOARDS = 1024 * 2.4e9 / (MOVEGEN_VALU_PER_BOARD * 4) / 1e6
 
 
@@ -381,7 +381,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": MOVEGEN_TRAFFIC_BYTES_PER_BOARD * n,
                          "kernel": "hive_piece_kernel<false>", "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_BOARD,
-                         "note": "VALU-issue bound (512 wave-instructions per board), not HBM bound: see saturated.valu_issue_roof; "
+                         "note": "VALU-issue bound (489 wave-instructions per board), not HBM bound: see saturated.valu_issue_roof; "
                                  "4096 boards = 256 workgroups x 11 waves = one workgroup per CU"},
             "overlapped_4_streams": overlapped,
             "saturated": sat,
