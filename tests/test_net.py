@@ -188,6 +188,23 @@ def test_trainer_bf16_autocast_close_to_fp32():
     assert l1 < l0
 
 
+def test_trainer_fused_kernels_need_the_gpu():
+    """The fused BatchNorm / convolution kernels are bf16 GPU code: on a CPU-resident net the default trainer runs the
+    plain modules, asking for the kernels explicitly fails loudly, and FusedTrainNet in eval mode is the net itself."""
+    from hive_alphazero_amd.alpha_net import ChessNet, FusedTrainNet, Trainer
+    torch.manual_seed(0)
+    net = ChessNet()
+    assert Trainer(net).fused is False
+    with pytest.raises(ValueError):
+        Trainer(net, fused=True)
+    net.eval()
+    x, _, _ = _toy_batch(2)
+    with torch.no_grad():
+        p0, v0 = net(x)
+        p1, v1 = FusedTrainNet(net)(x)
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)
+
+
 @pytest.mark.gpu
 def test_hip_resblock_matches_two_convs():
     """hive_nn_resblock (both convolutions of a residual block in one launch, intermediate in LDS) against the two
