@@ -372,7 +372,7 @@ class InferenceNet:
     conv = "hip" (default for bf16 on a GPU): the 39 3x3 convolutions run in the hand-written MFMA
     kernel hive_nn_conv3x3 with bias / skip / ReLU fused; conv = "torch": MIOpen through F.conv2d."""
 
-    def __init__(self, net, dtype=torch.bfloat16, device=None, use_graph=True, conv=None):
+    def __init__(self, net, dtype=torch.bfloat16, device=None, use_graph=True, conv=None, tune_gemms=True):
         dev = torch.device(device) if device is not None else next(net.parameters()).device
         self.device, self.dtype, self.use_graph = dev, dtype, use_graph and dev.type == "cuda"
         if conv is None:
@@ -380,6 +380,9 @@ class InferenceNet:
         if conv == "hip" and not (dev.type == "cuda" and dtype == torch.bfloat16):
             raise ValueError("the HIP convolution path is bf16 on a GPU")
         self.conv = conv
+        # large leaf batches: let PyTorch's TunableOp pick the hipBLASLt solutions of the head GEMMs once, before the graph
+        # is captured (the default heuristic runs the 1024 x 18432 x 1584 policy FC at 178 us, the tuned pick at 92 us)
+        self.tune_gemms = tune_gemms and dev.type == "cuda"
         self.fuse_blocks = True          # hive_nn_resblock: both convolutions of a residual block in one launch
         net = net.eval()
         cl = torch.channels_last
@@ -472,6 +475,25 @@ class InferenceNet:
         return torch.softmax(p, dim=1), v
 
     @torch.no_grad()
+    def _tune(self, static_in):
+        try:
+            import torch.cuda.tunable as tn
+        except ImportError:
+            return
+        import os
+        import tempfile
+        if not tn.is_enabled():
+            # the results file TunableOp writes at exit goes to the temp directory, not into the caller's cwd
+            tn.set_filename(os.path.join(tempfile.gettempdir(), "hive_tunableop_%d.csv" % os.getpid()))
+        tn.enable(True)                    # stays on: the recorded solutions are what later calls (and the graph) use
+        tn.set_max_tuning_duration(1000)
+        tn.tuning_enable(True)
+        try:
+            self._forward(static_in)
+            torch.cuda.synchronize(self.device)
+        finally:
+            tn.tuning_enable(False)
+
     def __call__(self, planes_hwc):
         with self._lock:
             p, v = self._call_locked(planes_hwc)
@@ -490,6 +512,8 @@ class InferenceNet:
             s = torch.cuda.Stream(self.device)
             s.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(s):
+                if self.tune_gemms and B >= 256:
+                    self._tune(static_in)
                 for _ in range(2):
                     self._forward(static_in)
             torch.cuda.current_stream(self.device).wait_stream(s)
