@@ -384,43 +384,68 @@ class InferenceNet:
         # is captured (the default heuristic runs the 1024 x 18432 x 1584 policy FC at 178 us, the tuned pick at 92 us)
         self.tune_gemms = tune_gemms and dev.type == "cuda"
         self.fuse_blocks = True          # hive_nn_resblock: both convolutions of a residual block in one launch
-        net = net.eval()
-        cl = torch.channels_last
         if conv == "hip":
             from . import _lib
             self._L = _lib.load()
+        for name, value in self._folded(net.eval()).items():
+            setattr(self, name, value)
+        self._graphs = {}
+        import threading
+        self._lock = threading.Lock()      # capture/replay share static buffers: one caller at a time
+
+    def _folded(self, net):
+        """Every weight tensor of the forward, BatchNorm folded, in the layouts the kernels read."""
+        dev, dtype, conv = self.device, self.dtype, self.conv
+        cl = torch.channels_last
+        out = {}
+        if conv == "hip":
             w, b = _fold(net.conv.conv1, net.conv.bn1)
-            self.h_stem = (_frag_major(w, dev), b.to(dev, torch.float32).contiguous())
-            self.h_blocks = []
+            out["h_stem"] = (_frag_major(w, dev), b.to(dev, torch.float32).contiguous())
+            h_blocks = []
             for i in range(19):
                 rb = getattr(net, "res_%i" % i)
                 w1, b1 = _fold(rb.conv1, rb.bn1)
                 w2, b2 = _fold(rb.conv2, rb.bn2)
-                self.h_blocks.append((_frag_major(w1, dev), b1.to(dev, torch.float32).contiguous(),
-                                      _frag_major(w2, dev), b2.to(dev, torch.float32).contiguous()))
+                h_blocks.append((_frag_major(w1, dev), b1.to(dev, torch.float32).contiguous(),
+                                 _frag_major(w2, dev), b2.to(dev, torch.float32).contiguous()))
+            out["h_blocks"] = h_blocks
 
         def prep(w, b):
             return (w.to(dev, dtype).contiguous(memory_format=cl), b.to(dev, dtype))
 
-        self.stem = prep(*_fold(net.conv.conv1, net.conv.bn1))
-        self.blocks = []
+        out["stem"] = prep(*_fold(net.conv.conv1, net.conv.bn1))
+        blocks = []
         for i in range(19):
             rb = getattr(net, "res_%i" % i)
-            self.blocks.append((prep(*_fold(rb.conv1, rb.bn1)), prep(*_fold(rb.conv2, rb.bn2))))
+            blocks.append((prep(*_fold(rb.conv1, rb.bn1)), prep(*_fold(rb.conv2, rb.bn2))))
+        out["blocks"] = blocks
         ob = net.outblock
         # the two 1x1 head convolutions are plain GEMMs over the NHWC activations ([B*144, 256] x [256, k])
         wv, bv = _fold(ob.conv, ob.bn)
         wp, bp = _fold(ob.conv1, ob.bn1)
-        self.vconv = (wv.reshape(1, 256).to(dev, dtype).contiguous(), bv.to(dev, dtype))
-        self.pconv = (wp.reshape(128, 256).to(dev, dtype).contiguous(), bp.to(dev, dtype))
+        out["vconv"] = (wv.reshape(1, 256).to(dev, dtype).contiguous(), bv.to(dev, dtype))
+        out["pconv"] = (wp.reshape(128, 256).to(dev, dtype).contiguous(), bp.to(dev, dtype))
         # the policy FC consumes the head in NHWC order: permute its columns once (c*144+hw -> hw*128+c)
         wfc = ob.fc.weight.detach().float().view(ACTIONS, 128, 144).permute(0, 2, 1).reshape(ACTIONS, 144 * 128)
-        self.fc = (wfc.to(dev, dtype).contiguous(), ob.fc.bias.detach().to(dev, dtype))
-        self.fc1 = (ob.fc1.weight.detach().to(dev, torch.float32), ob.fc1.bias.detach().to(dev, torch.float32))
-        self.fc2 = (ob.fc2.weight.detach().to(dev, torch.float32), ob.fc2.bias.detach().to(dev, torch.float32))
-        self._graphs = {}
-        import threading
-        self._lock = threading.Lock()      # capture/replay share static buffers: one caller at a time
+        out["fc"] = (wfc.to(dev, dtype).contiguous(), ob.fc.bias.detach().to(dev, dtype))
+        out["fc1"] = (ob.fc1.weight.detach().to(dev, torch.float32), ob.fc1.bias.detach().to(dev, torch.float32))
+        out["fc2"] = (ob.fc2.weight.detach().to(dev, torch.float32), ob.fc2.bias.detach().to(dev, torch.float32))
+        return out
+
+    def refresh(self, net):
+        """New weights (same architecture) after a training iteration -- what the reference's workers do by re-reading
+        the checkpoint (self_play.py:37-75): the folded tensors are copied INTO the existing buffers, so the captured
+        HIP graphs (which hold their addresses) and the tuned GEMM choices stay valid."""
+        def copy_into(dst, src):
+            if isinstance(dst, torch.Tensor):
+                dst.copy_(src)
+            else:
+                for d, s_ in zip(dst, src):
+                    copy_into(d, s_)
+        with self._lock, torch.no_grad():
+            for name, value in self._folded(net).items():
+                copy_into(getattr(self, name), value)
+            torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
 
     def _conv_hip(self, x, cin, w, b, res, out):
         import ctypes

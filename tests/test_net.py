@@ -394,3 +394,29 @@ def test_hip_training_conv_matches_torch(cin, weights_cl):
     assert (gw - conv.weight.grad).abs().max().item() <= 2 * tol(conv.weight.grad)
     if gb is not None:
         assert (gb - conv.bias.grad).abs().max().item() <= 1e-3 * conv.bias.grad.abs().max().item() + 1e-3
+
+
+@pytest.mark.gpu
+def test_inference_net_refresh_keeps_graphs_and_takes_new_weights():
+    """After a training iteration the evaluator takes the new weights in place (the reference's workers re-read the
+    checkpoint, self_play.py:37-75): the captured graph of a batch size keeps replaying, now with the new network."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    torch.manual_seed(1)
+    net_a = ChessNet().cuda().eval()
+    torch.manual_seed(2)
+    net_b = ChessNet().cuda().eval()
+    with torch.no_grad():                      # make the BatchNorm statistics differ too
+        for m in net_b.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.1, 0.1); m.running_var.uniform_(0.8, 1.2)
+    x = (torch.rand((32, 12, 12, 56), device="cuda") < 0.1).to(torch.bfloat16)
+    inf = InferenceNet(net_a)
+    pa, va = inf(x)
+    graphs = dict(inf._graphs)
+    inf.refresh(net_b)
+    pb, vb = inf(x)
+    assert inf._graphs == graphs and 32 in inf._graphs          # no re-capture
+    fresh_p, fresh_v = InferenceNet(net_b)(x)
+    assert torch.equal(pb, fresh_p) and torch.equal(vb, fresh_v)
+    assert (pa - pb).abs().max().item() > 1e-5                  # and it is not the old network any more
