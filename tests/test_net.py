@@ -340,7 +340,7 @@ def test_trainer_fused_bn_close_to_library_path():
         t.model.train()
         l = t.loss(x, pol, val)
         l.backward()
-        losses.append(float(l))
+        losses.append(float(l.detach()))
         grads.append(torch.cat([p.grad.flatten().float() for p in n.parameters()]))
     la, lb, lc = losses
     assert abs(la - lc) < 0.02 * abs(lc) + 0.02 and abs(lb - lc) < 0.02 * abs(lc) + 0.02
