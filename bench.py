@@ -121,7 +121,7 @@ def selfplay_measure(args, local_rank, world):
         "results": {"white": sp.white_wins, "black": sp.black_wins, "draw_or_cap": sp.draws},
     }
     sp.close()
-    if args.cpu_baseline_selfplay and int(os.environ.get("RANK", "0")) == 0:
+    if args.cpu_baseline_selfplay and world == 1:            # host baselines are an N = 1 measurement
         out["cpu_baseline"] = selfplay_cpu_baseline(args.sims)
     return out
 
@@ -390,7 +390,8 @@ def main():
             "training": training,
         }
         t_cpu0 = time.perf_counter()
-        if not args.no_cpu_baseline:
+        out["cpu_baseline"] = None                              # timed on rank 0 at N = 1 only
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(boards.cpu().numpy())
         # where the process's wall time goes (the timed region is only the K headline steps)
         out["wall_s"] = {"imports_and_corpus": round(t_setup, 2), "timed_region": round(wall_max, 4),
