@@ -136,7 +136,7 @@ def training_measure(steps, batch=512):
     pi = torch.softmax(torch.randn((batch, 1584), device="cuda", generator=g), 1)
     z = torch.sign(torch.randn((batch,), device="cuda", generator=g))
     torch.manual_seed(0)
-    tr = Trainer(ChessNet().cuda())
+    tr = Trainer(ChessNet().cuda(), ddp=False)
     for _ in range(3):
         tr.step(x, pi, z)
     torch.cuda.synchronize()
@@ -352,7 +352,7 @@ def main():
             selfplay["leaf_evals_per_s_all_gpus"] = round(float(t[1].item()), 1)
 
     training = None
-    if rank == 0 and args.train_steps > 0:
+    if world == 1 and args.train_steps > 0:                   # single-GPU side measurement (no DDP group to join)
         try:
             training = training_measure(args.train_steps)
         except Exception as exc:                 # a side measurement never takes the headline line down
