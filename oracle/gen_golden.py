@@ -22,6 +22,8 @@ Fixture families:
                      terminal flag/winner and the action taken
   mcts.json.gz       HivePlayer (SEARCH_THREADS=1, seeded numpy, stub evaluator)
                      visit counts / chosen action
+  mcts_deep.json.gz  the same at 600 simulations without root noise: searches deep enough
+                     to run through dict entries shared by two move orders
   net.json           ChessNet seeded-init output checksums
 """
 import argparse
@@ -386,6 +388,41 @@ def cmd_sl(a):
         json.dump({"cases": cases}, f, separators=(",", ":"))
 
 
+def cmd_mcts_deep(a):
+    """HivePlayer of the TRUE reference at 600 simulations without root noise from mid-game positions where several
+    descents run through tree entries shared by two move orders (the dict keyed by state_key): pins the transposition
+    behaviour that the 50-simulation cases of `mcts` never reach.  Minutes per case (the reference env is ~60 ms/move)."""
+    import contextlib
+    import io
+    import woker.solo_play as sp
+    sp.SEARCH_THREADS = 1
+    sp.noise_eps = 0.0
+    cases = []
+    for prefix_seed, plies in [(44, 24), (52, 24)]:
+        rng = np.random.default_rng(prefix_seed)
+        g = _new_game()
+        prefix = []
+        for _ in range(plies):
+            acts = g.actions()
+            act = int(acts[rng.integers(len(acts))])
+            prefix.append(act)
+            g.move(act)
+        player = sp.HivePlayer(pipes=[StubPipe()])
+        player.simulation_num_per_move = a.sims
+        np.random.seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            action, (policy, sum_all) = player.action(g)
+        root = player.tree[g.state_key]
+        cases.append({"prefix_seed": prefix_seed, "prefix": prefix, "sims": a.sims, "turn": int(g.state.turn),
+                      "action": int(action), "sum_all": float(sum_all),
+                      "policy_nz": [[i, float(x)] for i, x in enumerate(policy) if x != 0],
+                      "root_edges": [[int(k), int(v.n), float(v.w)] for k, v in root.a.items()],
+                      "tree_size": len(player.tree)})
+        print("case", prefix_seed, "turn", g.state.turn, "action", action, "sum_all", sum_all, "tree", len(player.tree), flush=True)
+    with gzip.open(os.path.join(GOLD, "mcts_deep.json.gz"), "wt", compresslevel=9) as f:
+        json.dump({"cases": cases}, f, separators=(",", ":"))
+
+
 def cmd_net(a):
     """alpha_zero/alpha_net.py::ChessNet: (1) same-seed init of the build's ChessNet gives identical
     tensors, (2) outputs of the reference net on planes of golden positions (CPU fp32)."""
@@ -441,6 +478,8 @@ if __name__ == "__main__":
     pg.add_argument("--passy", action="store_true", help="games with voluntary passes")
     pm = sub.add_parser("mcts")
     pm.add_argument("--sims", type=int, default=50)
+    pd = sub.add_parser("mcts_deep")
+    pd.add_argument("--sims", type=int, default=600)
     pn = sub.add_parser("net")
     pn.add_argument("--seed", type=int, default=0)
     pu = sub.add_parser("uct")
@@ -450,5 +489,5 @@ if __name__ == "__main__":
     ps.add_argument("--seed", type=int, default=4)
     sub.add_parser("sl")
     a = ap.parse_args()
-    {"tables": cmd_tables, "games": cmd_games, "mcts": cmd_mcts, "net": cmd_net, "uct": cmd_uct,
+    {"tables": cmd_tables, "games": cmd_games, "mcts": cmd_mcts, "mcts_deep": cmd_mcts_deep, "net": cmd_net, "uct": cmd_uct,
      "selfplay": cmd_selfplay, "sl": cmd_sl}[a.cmd](a)

@@ -117,3 +117,66 @@ def test_sl_get_buffer_gpu_env():
         for (state, policy, value, lens), row in zip(data, case["rows"]):
             assert int(zlib.crc32(np.asarray(state, dtype=np.float32).tobytes())) == row["crc"]
             assert value == row["v"] and lens == row["lens"]
+
+
+DEEP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mcts_deep.json.gz")
+
+
+def _deep_cases():
+    with gzip.open(DEEP, "rt") as f:
+        return json.load(f)["cases"]
+
+
+def test_hiveplayer_matches_reference_through_transpositions():
+    """600 simulations of the TRUE reference without root noise from mid-game positions (tests/golden/mcts_deep.json.gz,
+    oracle/gen_golden.py mcts_deep): deep enough that descents run through dict entries shared by two move orders.
+    The mirror over the oracle env must reproduce the root statistics, the policy, the move and the number of entries."""
+    import hive_alphazero_amd.solo_play as sp
+    from oracle_env import OracleGamePlay
+    sp.SEARCH_THREADS = 1
+    old_eps = sp.noise_eps
+    sp.noise_eps = 0.0
+    try:
+        for case in _deep_cases():
+            g = OracleGamePlay()
+            for a in case["prefix"]:
+                g.move(a)
+            assert g.state.turn == case["turn"]
+            player = sp.HivePlayer(pipes=[StubPipe()])
+            player.simulation_num_per_move = case["sims"]
+            np.random.seed(0)
+            action, (policy, sum_all) = player.action(g)
+            root = player.tree[g.state_key]
+            assert [[int(k), int(v.n), float(v.w)] for k, v in root.a.items()] == case["root_edges"]
+            assert action == case["action"] and float(sum_all) == case["sum_all"]
+            assert [[i, float(x)] for i, x in enumerate(policy) if x != 0] == case["policy_nz"]
+            assert len(player.tree) == case["tree_size"]
+    finally:
+        sp.noise_eps = old_eps
+
+
+@pytest.mark.gpu
+def test_gpu_search_matches_reference_through_transpositions():
+    """The same golden cases against the GPU tree search directly (hash-table merging on): policy within fp32
+    rounding of the reference's, same move and visit total; and the searches did go through shared entries."""
+    import torch
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd import batch, mcts
+    from hive_alphazero_amd.env_hive import GamePlay
+    from test_gpu_search import _host_stub_evaluator
+    for case in _deep_cases():
+        g = GamePlay(1050, 900)
+        for a in case["prefix"]:
+            g.move(a)
+        B = batch.BoardBatch(1)
+        B.import_state(g._rec.reshape(1, 64), g._hist.reshape(1, 384))
+        rb, rh = B.export_state()
+        ts = mcts.TreeSearch(1, case["sims"], _host_stub_evaluator, plane_dtype=torch.float32, noise_eps=0.0)
+        action, policy, sum_n = ts.search(rb, rh)
+        want = np.zeros(1584)
+        for i, x in case["policy_nz"]:
+            want[i] = x
+        assert np.abs(policy[0].cpu().numpy().astype(np.float64) - want).max() < 1e-6
+        assert int(action[0].item()) == case["action"] and float(sum_n[0].item()) == case["sum_all"]
+        assert int(ts.transposition_hits()[0].item()) >= 4
+        ts.close(); B.close()
