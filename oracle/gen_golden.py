@@ -423,6 +423,45 @@ def cmd_mcts_deep(a):
         json.dump({"cases": cases}, f, separators=(",", ":"))
 
 
+TRAIN_DIGEST_KEYS = ["conv.conv1.weight", "conv.bn1.weight", "conv.bn1.running_mean", "res_0.conv1.weight", "res_9.bn2.bias",
+                     "res_18.conv2.weight", "res_18.bn2.running_var", "outblock.fc.weight", "outblock.fc.bias",
+                     "outblock.fc2.weight", "outblock.bn.num_batches_tracked"]
+
+
+def train_dataset():
+    """The 20-row synthetic dataset of the `train` fixture (also rebuilt by tests/test_net.py)."""
+    rng = np.random.default_rng(7)
+    ds = np.empty((20, 3), dtype=object)
+    for i in range(20):
+        ds[i, 0] = (rng.random((12, 12, 56)) < 0.1).astype(np.float32)
+        p = rng.random(1584).astype(np.float32)
+        ds[i, 1] = p / p.sum()
+        ds[i, 2] = float(rng.choice([-1.0, 1.0]))
+    return ds
+
+
+def cmd_train(a):
+    """alpha_zero/alpha_net.py::train (fp32, CPU): one epoch of ten batches of two rows from a seeded init; the fixture
+    holds the reported loss and sums of a few tensors of the trained network (data, no weights)."""
+    import contextlib
+    import io
+    import torch
+    from alpha_zero.alpha_net import ChessNet, train
+    os.makedirs("model_data", exist_ok=True)
+    torch.manual_seed(3)
+    net = ChessNet()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        train(net, train_dataset(), 0, 1, cpu=5, batch_size=2)
+    line = [l for l in buf.getvalue().splitlines() if "total loss per batch" in l][-1]
+    loss = float(line.rsplit(":", 1)[1])
+    sd = net.state_dict()
+    digest = {k: [float(sd[k].double().sum()), float((sd[k].double() ** 2).sum())] for k in TRAIN_DIGEST_KEYS}
+    with open(os.path.join(GOLD, "train.json"), "w") as f:
+        json.dump({"init_seed": 3, "cpu": 5, "batch_size": 2, "epochs": 1, "printed_loss_3dp": loss, "digest": digest}, f, indent=1)
+    print("loss", loss, "fc.bias", digest["outblock.fc.bias"])
+
+
 def cmd_net(a):
     """alpha_zero/alpha_net.py::ChessNet: (1) same-seed init of the build's ChessNet gives identical
     tensors, (2) outputs of the reference net on planes of golden positions (CPU fp32)."""
@@ -480,6 +519,7 @@ if __name__ == "__main__":
     pm.add_argument("--sims", type=int, default=50)
     pd = sub.add_parser("mcts_deep")
     pd.add_argument("--sims", type=int, default=600)
+    sub.add_parser("train")
     pn = sub.add_parser("net")
     pn.add_argument("--seed", type=int, default=0)
     pu = sub.add_parser("uct")
@@ -489,5 +529,5 @@ if __name__ == "__main__":
     ps.add_argument("--seed", type=int, default=4)
     sub.add_parser("sl")
     a = ap.parse_args()
-    {"tables": cmd_tables, "games": cmd_games, "mcts": cmd_mcts, "mcts_deep": cmd_mcts_deep, "net": cmd_net, "uct": cmd_uct,
+    {"tables": cmd_tables, "games": cmd_games, "mcts": cmd_mcts, "mcts_deep": cmd_mcts_deep, "train": cmd_train, "net": cmd_net, "uct": cmd_uct,
      "selfplay": cmd_selfplay, "sl": cmd_sl}[a.cmd](a)

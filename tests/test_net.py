@@ -420,3 +420,29 @@ def test_inference_net_refresh_keeps_graphs_and_takes_new_weights():
     fresh_p, fresh_v = InferenceNet(net_b)(x)
     assert torch.equal(pb, fresh_p) and torch.equal(vb, fresh_v)
     assert (pa - pb).abs().max().item() > 1e-5                  # and it is not the old network any more
+
+
+def test_train_matches_reference_training_run_cpu():
+    """alpha_net.train against the TRUE reference's train() (tests/golden/train.json, oracle/gen_golden.py train): same
+    seeded init, the same 20 synthetic rows, one epoch of ten batches of two on the CPU in fp32 -- the reported loss
+    (the reference prints it with three decimals) and sums / sums of squares of tensors of the trained network, incl.
+    BatchNorm running statistics and the step counter."""
+    from hive_alphazero_amd.alpha_net import ChessNet, train
+    with open(os.path.join(GOLD, "train.json")) as f:
+        gold = json.load(f)
+    rng = np.random.default_rng(7)
+    ds = np.empty((20, 3), dtype=object)
+    for i in range(20):
+        ds[i, 0] = (rng.random((12, 12, 56)) < 0.1).astype(np.float32)
+        p = rng.random(1584).astype(np.float32)
+        ds[i, 1] = p / p.sum()
+        ds[i, 2] = float(rng.choice([-1.0, 1.0]))
+    torch.manual_seed(gold["init_seed"])
+    net = ChessNet()
+    losses = train(net, ds, 0, gold["epochs"], cpu=gold["cpu"], batch_size=gold["batch_size"], log=lambda *_: None)
+    assert abs(losses[0] - gold["printed_loss_3dp"]) < 1e-3
+    sd = net.state_dict()
+    for k, (s1, s2) in gold["digest"].items():
+        t = sd[k].double()
+        assert abs(float(t.sum()) - s1) <= 1e-4 * max(1.0, abs(s1)), k
+        assert abs(float((t ** 2).sum()) - s2) <= 1e-4 * max(1.0, abs(s2)), k
