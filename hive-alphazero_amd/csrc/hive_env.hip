@@ -119,8 +119,7 @@ struct PieceInfo {
 // own == true : get_actions semantics (env_hive.py:207-285)
 // own == false: mini_black_actions semantics for an enemy piece (env_hive.py:449-485)
 template <int ANT_STEPS>
-__device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint32_t *occ_p, const uint32_t *topw_p,
-                                                 const uint8_t *pinfo, const uint32_t *pinmask_p, const int *pin_done_p,
+__device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint32_t *occ_p, const uint8_t *pinfo, const uint32_t *pinmask_p, const int *pin_done_p,
                                                  const uint32_t *place_p, int q, int type, bool own, bool valid)
 {
     PieceInfo out;
@@ -502,7 +501,7 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     bool own;
     if (!FULL) { q = stm * 11 + wv; own = true; }
     else { int col = item >> 3; q = col * 11 + wv; own = (col == stm); }
-    PieceInfo pc = piece_dests<HIVE_ANT_STEPS>(st, sm.occ[bl], sm.topw[bl], sm.pinfo[bl], &sm.pinmask[bl], &sm.pin_done, sm.place[bl], q,
+    PieceInfo pc = piece_dests<HIVE_ANT_STEPS>(st, sm.occ[bl], sm.pinfo[bl], &sm.pinmask[bl], &sm.pin_done, sm.place[bl], q,
                                                            type, own, valid);
     HIVE_STAMP(1);
     if (own && (mask != nullptr || count != nullptr)) {
