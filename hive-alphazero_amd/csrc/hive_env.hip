@@ -802,7 +802,8 @@ struct HiveBatch {
     uint32_t *legal = nullptr;              // cached legal mask of the current positions
     int32_t *legal_count = nullptr;
     int16_t *legal_list = nullptr;
-    bool legal_valid = false;
+    bool legal_valid = false;               // legal / legal_count describe the current positions
+    bool list_valid = false;                // ... and so does legal_list (built only when somebody asks for it)
     unsigned long long *feat = nullptr;     // packed-feature workspace of the encoder
     unsigned long long *illegal = nullptr;  // device counter
 };
@@ -969,19 +970,28 @@ int hive_batch_reset(HiveBatch *h, const int32_t *idx, int k)
     return HIVE_OK;
 }
 
-static int ensure_legal(HiveBatch *h)
+static int ensure_legal(HiveBatch *h, bool want_list)
 {
-    if (h->legal_valid) return HIVE_OK;
-    int rc = launch_pieces(h->boards, h->n, h->legal, h->legal_count, h->legal_list, h->stream);
-    if (rc == HIVE_OK) h->legal_valid = true;
-    return rc;
+    if (!h->legal_valid) {
+        int rc = launch_pieces(h->boards, h->n, h->legal, h->legal_count, nullptr, h->stream);
+        if (rc != HIVE_OK) return rc;
+        h->legal_valid = true;
+        h->list_valid = false;
+    }
+    if (want_list && !h->list_valid) {
+        hipLaunchKernelGGL(hive_list_kernel, dim3((unsigned)((h->n + 3) / 4)), dim3(256), 0, h->stream, h->legal, h->n,
+                           h->legal_list);
+        HIP_TRY(hipGetLastError());
+        h->list_valid = true;
+    }
+    return HIVE_OK;
 }
 
 int hive_batch_legal(HiveBatch *h, uint32_t *mask, int32_t *count, int16_t *list)
 {
     if (!h) return fail(HIVE_E_ARG, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    int rc = ensure_legal(h);
+    int rc = ensure_legal(h, list != nullptr);
     if (rc != HIVE_OK) return rc;
     size_t n = (size_t)h->n;
     if (mask) HIP_TRY(hipMemcpyAsync(mask, h->legal, sizeof(uint32_t) * HIVE_MASK_WORDS * n, hipMemcpyDeviceToDevice, h->stream));
@@ -1005,7 +1015,7 @@ int hive_batch_step(HiveBatch *h, const int32_t *actions, int sync)
 {
     if (!h || !actions) return fail(HIVE_E_ARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    int rc = ensure_legal(h);
+    int rc = ensure_legal(h, false);       // the step only checks the action against the destination boards
     if (rc != HIVE_OK) return rc;
     int64_t before = 0;
     if (sync) { rc = hive_batch_illegal_count(h, &before); if (rc != HIVE_OK) return rc; }
