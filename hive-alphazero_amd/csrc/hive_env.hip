@@ -2,11 +2,14 @@
 //
 // Work decomposition: a (board, piece) pair is one DPP quad -- the 144-bit
 // boards are spread over three lanes (hive_bb.hpp) -- so a wavefront carries 16 pairs.  A
-// workgroup is 11 waves, wave w = piece slot w, hence every wave runs exactly one piece type
-// (no type divergence); it owns 16 boards (movegen) or 8 boards x both colours (planes).
-// The packed records and the occupancy / top-colour boards are staged in LDS; per-piece
-// destination boards go back to LDS and are turned into the 1584-bit legal mask with 25 wave
-// ballots per board (mbcnt prefix sums give the sorted id list).
+// workgroup is 11 waves, each working on one piece slot, hence every wave runs exactly one piece
+// type (no type divergence); it owns 16 boards (movegen) or 8 boards x both colours (planes).
+// The packed records, the occupancy / top-colour boards and the per-cell piece sets are staged in
+// LDS; three of the waves first settle the one-hive question for all pieces of the workgroup on the
+// 22-node piece graph (one lane per piece) and build the per-board placement / next_move_tiles
+// boards; every (board, slot) quad writes its destination board straight to HBM -- the legal set in
+// the reference's pre_actions form; hive_list_kernel turns it into the ascending id list with wave
+// ballots and mbcnt prefix sums when a caller asks for it.
 //
 // Reference semantics implemented here (paths relative to the reference root):
 //   env_hive.py:196-304   pre_actions / get_actions / encode_action
