@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "hive_search_create", "hive_search_destroy", "hive_search_set_stream", "hive_search_set_params",
     "hive_search_set_roots", "hive_search_select", "hive_search_backup", "hive_search_policy",
     "hive_search_node_counts", "hive_search_set_transpositions", "hive_search_transposition_hits",
+    "hive_search_set_game_ids", "hive_search_root_stats", "hive_search_leaf_histogram", "hive_search_sample_noise",
     # include/hive_nn.h
     "hive_nn_conv3x3", "hive_nn_resblock", "hive_nn_bn_workspace_floats", "hive_nn_bn_act_fwd", "hive_nn_bn_act_bwd",
     "hive_nn_pack_conv3x3_weights",
@@ -102,6 +103,11 @@ def load():
     L.hive_search_node_counts.argtypes = [vp, vp]
     L.hive_search_set_transpositions.argtypes = [vp, i32]
     L.hive_search_transposition_hits.argtypes = [vp, vp]
+    L.hive_search_set_game_ids.argtypes = [vp, vp]
+    L.hive_search_root_stats.argtypes = [vp, vp, vp, vp]
+    L.hive_search_leaf_histogram.argtypes = [vp, vp]
+    L.hive_search_sample_noise.argtypes = [ctypes.c_uint64, ctypes.c_int64, i32, ctypes.c_float, i32, i32, vp, ctypes.c_float,
+                                           vp, vp]
     L.hive_nn_conv3x3.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp]
     L.hive_nn_resblock.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
     f32, i64 = ctypes.c_float, ctypes.c_longlong

@@ -41,6 +41,8 @@ struct SearchDev {
     int32_t *tt;                                   // [G][TT] open-addressing table position -> node (-1 empty)
     int32_t *tt_hits;                              // [G] descents that continued through a transposition (statistics)
     int TT, merge;                                 // table size (power of two), merging on/off
+    long long *game_id;                            // [G] global game index: the only per-game key of the noise streams
+    int32_t *kind_hist;                            // [G][8] leaves by LeafKind since create (statistics)
 };
 
 // ------------------------------------------------------------------ small device helpers
@@ -82,6 +84,15 @@ struct Rng {
     }
 };
 
+// noise key of one draw: (search seed, global game id, turn of the root position, simulation of this search, in-flight
+// slot, edge) -- nothing that depends on where in a batch, on which GPU or after how many other searches the game runs
+__device__ __forceinline__ Rng noise_rng(unsigned long long seed, long long game, unsigned turn, unsigned long long sim,
+                                         int slot, int e)
+{
+    return Rng(seed, (unsigned long long)game, ((unsigned long long)turn << 40) | (sim * 8ull + (unsigned long long)slot),
+               (unsigned long long)e);
+}
+
 __device__ __forceinline__ float wave_sum(float x)
 {
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -111,6 +122,38 @@ __device__ __forceinline__ void wave_copy(void *dst, const void *src, int bytes,
     const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
     uint32_t *d = reinterpret_cast<uint32_t *>(dst);
     for (int i = lane; i < bytes / 4; i += 64) d[i] = s[i];
+}
+
+// eta ~ Dirichlet(alpha) over the ne edges of one node, edge e = lane + 64 k in noise[k] (np.random.dirichlet,
+// solo_play.py:322-323): independent Gamma(alpha, 1) draws divided by their sum
+__device__ __forceinline__ void wave_dirichlet(float noise[4], int ne, float alpha, unsigned long long seed, long long game,
+                                               unsigned turn, unsigned long long sim, int slot, int lane)
+{
+    float tot = 0.f;
+    for (int k = 0; k < 4; ++k) {
+        const int e = lane + 64 * k;
+        noise[k] = 0.f;
+        if (e < ne) {
+            Rng r = noise_rng(seed, game, turn, sim, slot, e);
+            noise[k] = r.gamma(alpha);
+            tot += noise[k];
+        }
+    }
+    tot = wave_sum(tot);
+    const float inv = tot > 0.f ? 1.0f / tot : 0.f;
+    for (int k = 0; k < 4; ++k) noise[k] *= inv;
+}
+
+// child_Q() + child_U() of alpha_zero/MCTS_chess.py:52-57 for one edge, in the reference's fp32 operation order
+// (numpy float32 arrays; math.sqrt(number_visits) enters as a float32 scalar): W/(1+N) + sqrtN * (|P|/(1+N)).
+// No fused multiply-add: the sum must round like numpy's separate multiply and add.
+__device__ __forceinline__ float uct_score(float w, float n, float p, float sqrt_visits)
+{
+#pragma clang fp contract(off)
+    const float d = 1.0f + n;
+    const float q = w / d;
+    const float u = sqrt_visits * (fabsf(p) / d);
+    return q + u;
 }
 
 // The reference keeps its tree in a dict keyed by GamePlay.state_key (solo_play.py:167-197, env_hive.py:70-94,151-168):
@@ -210,28 +253,21 @@ search_select_kernel(SearchDev S, int slot, unsigned long long sim, HiveBoard *_
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     int node = 0, depth = 0, kind = LEAF_NONE, leafnode = 0, leafedge = 0;
+    const unsigned root_turn = reinterpret_cast<const uint8_t *>(st)[33];
     while (true) {
         if (S.node_term[nbase + node]) { kind = LEAF_TERMINAL; leafnode = node; break; }          // game over (solo_play.py:169-180)
         if ((int)reinterpret_cast<const uint8_t *>(st)[33] >= S.prm.max_game_length) { kind = LEAF_CAPDRAW; break; }   // :181-183
         const int ne = S.node_nedge[nbase + node];
         const long long eb = (nbase + node) * EC;
+        const bool uct = S.prm.mode == HIVE_SEARCH_UCT;
+        // PUCT: sqrt(sum_n + 1) (solo_play.py:316).  UCT: sqrt(number_visits) of this node (MCTS_chess.py:55-57) -- every
+        // backup through a node passes one of its edges except the one that expanded it, so number_visits = sum_n + 1 too
         const float xx = sqrtf((float)S.node_sum_n[nbase + node] + 1.0f);
         // fresh Dirichlet noise on the root priors for every simulation (solo_play.py:322-323)
         float noise[4] = {0.f, 0.f, 0.f, 0.f};
-        if (depth == 0) {
-            float tot = 0.f;
-            for (int k = 0; k < 4; ++k) {
-                int e = lane + 64 * k;
-                if (e < ne) {
-                    Rng r(S.seed, (unsigned long long)g, sim * 8ull + (unsigned long long)slot, (unsigned long long)e);
-                    noise[k] = r.gamma(S.prm.dirichlet_alpha);
-                    tot += noise[k];
-                }
-            }
-            tot = wave_sum(tot);
-            float inv = tot > 0.f ? 1.0f / tot : 0.f;
-            for (int k = 0; k < 4; ++k) noise[k] *= inv;
-        }
+        const bool noisy = depth == 0 && !uct && S.prm.noise_eps > 0.f;
+        if (noisy)
+            wave_dirichlet(noise, ne, S.prm.dirichlet_alpha, S.seed, S.game_id[g], root_turn, sim, slot, lane);
         float best = -3.0e38f;
         int bidx = 0x7FFFFFFF;
         for (int k = 0; k < 4; ++k) {
@@ -239,9 +275,14 @@ search_select_kernel(SearchDev S, int slot, unsigned long long sim, HiveBoard *_
             if (e < ne) {
                 float p = S.e_p[eb + e], w = S.e_w[eb + e];
                 int n = S.e_n[eb + e];
-                float q = n > 0 ? w / (float)n : 0.f;
-                if (depth == 0) p = (1.0f - S.prm.noise_eps) * p + S.prm.noise_eps * noise[k];
-                float b = q + S.prm.c_puct * p * xx / (1.0f + (float)n);
+                float b;
+                if (uct) {
+                    b = uct_score(w, (float)n, p, xx);
+                } else {
+                    float q = n > 0 ? w / (float)n : 0.f;
+                    if (noisy) p = (1.0f - S.prm.noise_eps) * p + S.prm.noise_eps * noise[k];
+                    b = q + S.prm.c_puct * p * xx / (1.0f + (float)n);
+                }
                 if (b > best) { best = b; bidx = e; }
             }
         }
@@ -252,7 +293,7 @@ search_select_kernel(SearchDev S, int slot, unsigned long long sim, HiveBoard *_
             // virtual loss (solo_play.py:205-208)
             S.node_sum_n[nbase + node] += 1;
             S.e_n[eb + bidx] += 1;
-            S.e_w[eb + bidx] -= 1.0f;
+            S.e_w[eb + bidx] -= S.prm.virtual_loss;
             pnode[depth] = node;
             pedge[depth] = bidx;
             apply_action(reinterpret_cast<HiveBoard *>(st), reinterpret_cast<HiveHistory *>(st + 16), S.e_act[eb + bidx]);
@@ -313,15 +354,18 @@ search_backup_kernel(SearchDev S, int slot, const HiveBoard *__restrict__ leaf_b
                 long long eb = (nbase + pnode[d]) * EC + pedge[d];
                 S.node_sum_n[nbase + pnode[d]] -= 1;
                 S.e_n[eb] -= 1;
-                S.e_w[eb] += 1.0f;
+                S.e_w[eb] += S.prm.virtual_loss;
             }
+        if (lane == 0) S.kind_hist[g * 8 + LEAF_COLLISION] += 1;
         return;
     }
+    const bool uct = S.prm.mode == HIVE_SEARCH_UCT;
 
     float ret;
     int known = -1;
     const bool capped = kind == LEAF_CAPDRAW ||
                         (kind == LEAF_EXPAND && !over[g] && (int)leaf_boards[g].turn >= S.prm.max_game_length);
+    int stat = kind;                                        // hive_search_leaf_histogram bucket
     if (kind == LEAF_EXPAND && !capped && S.merge)          // another in-flight slot may have created this position meanwhile
         known = tt_find(S, g, reinterpret_cast<const uint32_t *>(&leaf_boards[g]), lane);
     if (kind == LEAF_TERMINAL) {
@@ -329,10 +373,12 @@ search_backup_kernel(SearchDev S, int slot, const HiveBoard *__restrict__ leaf_b
     } else if (capped) {
         // length cap (solo_play.py:181-183): a property of this path's turn count, not of the position -- no node
         if (kind == LEAF_EXPAND && lane == 0) S.e_child[(nbase + S.leaf_node[sg]) * EC + S.leaf_edge[sg]] = -1;
-        ret = kDrawSentinel;
+        ret = uct ? 0.f : kDrawSentinel;                    // (UCT has no cap; 250 plies only guard the 8-bit turn counter)
+        if (kind == LEAF_EXPAND) stat = 6;
     } else if (known >= 0) {
         if (lane == 0) S.e_child[(nbase + S.leaf_node[sg]) * EC + S.leaf_edge[sg]] = known;
         ret = S.node_term[nbase + known] ? S.node_tv[nbase + known] : v[g];
+        stat = 7;
     } else {
         const int id = (kind == LEAF_ROOT) ? 0 : S.n_nodes[g];
         wave_copy(&S.node_board[nbase + id], &leaf_boards[g], sizeof(HiveBoard), lane);
@@ -342,10 +388,16 @@ search_backup_kernel(SearchDev S, int slot, const HiveBoard *__restrict__ leaf_b
         const int stm = (turn & 1u) ? 0 : 1;
         bool term = false;
         float tv = 0.f;
-        if (over[g]) {                                      // solo_play.py:169-180
+        if (over[g] && uct) {
+            // MCTS_chess.py:144-146: a finished game is never expanded; every visit backs up the network's value of
+            // that same position -- the evaluator is a pure function of the planes, so the value is kept with the node
+            term = true;
+            tv = v[g];
+        } else if (over[g]) {                               // solo_play.py:169-180
             term = true;
             int w = winner[g];
             tv = (w == 0) ? kDrawSentinel : ((w - 1) == stm ? 1.0f : -1.0f);
+            stat = 6;
         } else if ((int)turn >= S.prm.max_game_length) {    // solo_play.py:181-183
             term = true;
             tv = kDrawSentinel;
@@ -364,7 +416,7 @@ search_backup_kernel(SearchDev S, int slot, const HiveBoard *__restrict__ leaf_b
                 if (a < HIVE_ACTIONS && HIVE_MASK_TEST(m, a)) { legal_bits |= 1u << t; tot += pg[a]; }
             }
             tot = wave_sum(tot) + 1e-8f;                    // solo_play.py:305-312
-            const float inv = 1.0f / tot;
+            const float inv = uct ? 1.0f : 1.0f / tot;      // MCTS_chess.py:89-94: illegal priors zeroed, no renormalisation
             int total = 0;
             for (int t = 0; t < 25; ++t) {
                 const bool mine = (legal_bits >> t) & 1u;
@@ -383,10 +435,14 @@ search_backup_kernel(SearchDev S, int slot, const HiveBoard *__restrict__ leaf_b
                 total += __popcll(w);
             }
             ne = total < EC ? total : EC;
-            if (ne == 0 && lane == 0) {                     // no legal move: the pass edge (solo_play.py:299-300)
-                S.e_act[eb] = -1; S.e_p[eb] = 0.f; S.e_n[eb] = 0; S.e_w[eb] = 0.f; S.e_child[eb] = -1;
+            if (ne == 0 && uct) {
+                // MCTS_chess.py:87-88: is_expanded stays False, the node is evaluated again on every visit (same value)
+                term = true;
+                tv = v[g];
+            } else if (ne == 0) {                           // no legal move: the pass edge (solo_play.py:299-300)
+                if (lane == 0) { S.e_act[eb] = -1; S.e_p[eb] = 0.f; S.e_n[eb] = 0; S.e_w[eb] = 0.f; S.e_child[eb] = -1; }
+                ne = 1;
             }
-            if (ne == 0) ne = 1;
         }
         if (lane == 0) {
             S.node_nedge[nbase + id] = ne;
@@ -399,20 +455,33 @@ search_backup_kernel(SearchDev S, int slot, const HiveBoard *__restrict__ leaf_b
         ret = term ? tv : v[g];
     }
     if (lane == 0) {
-        float val = ret;
-        for (int d = plen - 1; d >= 0; --d) {
-            long long eidx = (nbase + pnode[d]) * EC + pedge[d];
-            bool reach_max = (val == kDrawSentinel);        // solo_play.py:219-223
-            float leaf_v = reach_max ? -1.0f : -val;
-            S.e_w[eidx] += 1.0f + leaf_v;                   // virtual_loss + leaf_v; n and sum_n: -vl + 1 = 0
-            val = reach_max ? kDrawSentinel : leaf_v;       // solo_play.py:244-247
+        S.kind_hist[g * 8 + stat] += 1;
+        const float vl = S.prm.virtual_loss;
+        if (uct) {
+            // MCTS_chess.py:111-119: every node from the leaf up to the root gets number_visits += 1 (done at selection)
+            // and total_value += v if black is to move AT that node, -v if white is -- i.e. the edge leaving a position
+            // with white to move (odd turn) collects +v
+            for (int d = plen - 1; d >= 0; --d) {
+                const long long eidx = (nbase + pnode[d]) * EC + pedge[d];
+                const float sv = (S.node_board[nbase + pnode[d]].turn & 1u) ? ret : -ret;
+                S.e_w[eidx] = vl != 0.f ? S.e_w[eidx] + (vl + sv) : S.e_w[eidx] + sv;
+            }
+        } else {
+            float val = ret;
+            for (int d = plen - 1; d >= 0; --d) {
+                long long eidx = (nbase + pnode[d]) * EC + pedge[d];
+                bool reach_max = (val == kDrawSentinel);    // solo_play.py:219-223
+                float leaf_v = reach_max ? -1.0f : -val;
+                S.e_w[eidx] += vl + leaf_v;                 // virtual_loss + leaf_v; n and sum_n: -vl + 1 = 0
+                val = reach_max ? kDrawSentinel : leaf_v;   // solo_play.py:244-247
+            }
         }
     }
 }
 
 // solo_play.py:337-374 + self_play.py:139-157
 __global__ void __launch_bounds__(256)
-search_policy_kernel(SearchDev S, unsigned long long sim, float *__restrict__ policy, int32_t *__restrict__ action,
+search_policy_kernel(SearchDev S, float *__restrict__ policy, int32_t *__restrict__ action,
                      int32_t *__restrict__ sum_n_out, int selfplay)
 {
     const int lane = threadIdx.x & 63;
@@ -434,7 +503,10 @@ search_policy_kernel(SearchDev S, unsigned long long sim, float *__restrict__ po
     }
     nsum = wave_sum_i(nsum);
     wmax = wave_max(wmax);
-    const bool use_prior = (wmax < 0.f) || nsum == 0;      // solo_play.py:372-373
+    // solo_play.py:372-373 (HivePlayer falls back to the priors when every W is negative); MCTS_chess.py:157-161
+    // (get_policy) has no such rule -- before the first backed-up visit its policy is all zero
+    const bool uct = S.prm.mode == HIVE_SEARCH_UCT;
+    const bool use_prior = uct ? false : ((wmax < 0.f) || nsum == 0);
     float pi[4];
     float best = -1.f;
     int bidx = 0x7FFFFFFF;
@@ -442,7 +514,7 @@ search_policy_kernel(SearchDev S, unsigned long long sim, float *__restrict__ po
         int e = lane + 64 * k;
         pi[k] = 0.f;
         if (e < ne) {
-            pi[k] = use_prior ? S.e_p[eb + e] : (float)S.e_n[eb + e] / (float)nsum;
+            pi[k] = use_prior ? S.e_p[eb + e] : (nsum > 0 ? (float)S.e_n[eb + e] / (float)nsum : 0.f);
             int a = S.e_act[eb + e];
             if (pol && a >= 0) pol[a] = pi[k];
             if (pi[k] > best) { best = pi[k]; bidx = e; }
@@ -460,7 +532,7 @@ search_policy_kernel(SearchDev S, unsigned long long sim, float *__restrict__ po
                 int e = lane + 64 * k;
                 nz[k] = 0.f;
                 if (e < ne) {
-                    Rng r(S.seed ^ 0xD1B54A32D192ED03ull, (unsigned long long)g, sim, (unsigned long long)e);
+                    Rng r = noise_rng(S.seed ^ 0xD1B54A32D192ED03ull, S.game_id[g], turn, 0ull, 0, e);
                     nz[k] = r.gamma(0.5f);
                     tot += nz[k];
                 }
@@ -469,7 +541,7 @@ search_policy_kernel(SearchDev S, unsigned long long sim, float *__restrict__ po
             float inv = tot > 0.f ? 1.0f / tot : 0.f, psum = 0.f;
             for (int k = 0; k < 4; ++k) { nz[k] = (1.0f - err) * pi[k] + err * nz[k] * inv; psum += nz[k]; }
             psum = wave_sum(psum);
-            Rng r(S.seed ^ 0xA24BAED4963EE407ull, (unsigned long long)g, sim, 7777ull);
+            Rng r = noise_rng(S.seed ^ 0xA24BAED4963EE407ull, S.game_id[g], turn, 0ull, 0, 7777);
             float target = r.uniform() * psum;
             // inclusive prefix over edges in index order: lanes hold e = lane + 64k, so scan k-major
             float acc = 0.f;
@@ -496,6 +568,49 @@ search_policy_kernel(SearchDev S, unsigned long long sim, float *__restrict__ po
     }
 }
 
+// UCTNode.child_number_visits / child_total_value / child_priors of the root (MCTS_chess.py:33-35) as dense action-indexed rows
+__global__ void __launch_bounds__(256)
+search_root_stats_kernel(SearchDev S, float *__restrict__ visits, float *__restrict__ total_value, float *__restrict__ priors)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= S.G) return;
+    const long long row = (long long)g * HIVE_ACTIONS;
+    for (int i = lane; i < HIVE_ACTIONS; i += 64) {
+        if (visits) visits[row + i] = 0.f;
+        if (total_value) total_value[row + i] = 0.f;
+        if (priors) priors[row + i] = 0.f;
+    }
+    if (!S.active[g] || S.n_nodes[g] == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const long long eb = (long long)g * S.MN * EC;
+    const int ne = S.node_term[(long long)g * S.MN] ? 0 : S.node_nedge[(long long)g * S.MN];
+    for (int e = lane; e < ne; e += 64) {
+        const int a = S.e_act[eb + e];
+        if (a < 0) continue;
+        if (visits) visits[row + a] = (float)S.e_n[eb + e];
+        if (total_value) total_value[row + a] = S.e_w[eb + e];
+        if (priors) priors[row + a] = S.e_p[eb + e];
+    }
+}
+
+// hive_search_sample_noise: one wave per draw, the same wave_dirichlet / mixing arithmetic as search_select_kernel
+__global__ void __launch_bounds__(256)
+search_noise_kernel(unsigned long long seed, long long first_game, unsigned turn, float alpha, int k, int draws,
+                    const float *__restrict__ prior, float eps, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (d >= draws) return;
+    float noise[4];
+    wave_dirichlet(noise, k, alpha, seed, first_game + d, turn, 0ull, 0, lane);
+    for (int j = 0; j < 4; ++j) {
+        const int e = lane + 64 * j;
+        if (e < k) out[(long long)d * k + e] = prior ? (1.0f - eps) * prior[e] + eps * noise[j] : noise[j];
+    }
+}
+
 }  // namespace hive
 
 // ====================================================================== host side / C ABI
@@ -515,7 +630,7 @@ struct HiveSearch {
     int device = 0;
     hipStream_t stream = nullptr;
     unsigned long long sim = 0;
-    void *pool[32];
+    void *pool[40];
     int npool = 0;
 };
 
@@ -560,6 +675,17 @@ static int search_alloc(HiveSearch *s, int games, int max_nodes, int slots)
     d.merge = 1;
     S_TRY(alloc(s, &d.tt, (size_t)games * d.TT));
     S_TRY(alloc(s, &d.tt_hits, (size_t)games));
+    S_TRY(alloc(s, &d.game_id, (size_t)games));
+    S_TRY(alloc(s, &d.kind_hist, (size_t)games * 8));
+    S_TRY(hipMemset(d.kind_hist, 0, sizeof(int32_t) * (size_t)games * 8));
+    {
+        long long *ids = new (std::nothrow) long long[games];
+        if (ids == nullptr) return hive::set_error(HIVE_E_DEVICE, "hive_search_create: out of host memory");
+        for (int i = 0; i < games; ++i) ids[i] = i;
+        hipError_t e = hipMemcpy(d.game_id, ids, sizeof(long long) * (size_t)games, hipMemcpyHostToDevice);
+        delete[] ids;
+        S_TRY(e);
+    }
     S_TRY(hipMemset(d.tt, 0xFF, sizeof(int32_t) * (size_t)games * d.TT));
     S_TRY(hipMemset(d.tt_hits, 0, sizeof(int32_t) * games));
     S_TRY(hipMemset(d.n_nodes, 0, sizeof(int32_t) * games));
@@ -587,7 +713,7 @@ int hive_search_create(int games, int max_nodes, int slots, int device, uint64_t
     if (s == nullptr) return hive::set_error(HIVE_E_DEVICE, "hive_search_create: out of host memory");
     s->device = device;
     s->d.G = games; s->d.MN = max_nodes; s->d.L = slots; s->d.seed = seed;
-    s->d.prm = HiveSearchParams{0.7f, 0.25f, 0.3f, 55};
+    s->d.prm = HiveSearchParams{0.7f, 0.25f, 0.3f, 55, HIVE_SEARCH_PUCT, 1.0f};
     int rc = search_alloc(s, games, max_nodes, slots);
     if (rc != HIVE_OK) {            // free whatever was allocated; the caller never sees a partial handle
         hive_search_destroy(s);
@@ -616,6 +742,9 @@ int hive_search_set_stream(HiveSearch *s, void *stream)
 int hive_search_set_params(HiveSearch *s, const HiveSearchParams *p)
 {
     if (!s || !p) return hive::set_error(HIVE_E_ARG, "null argument");
+    if ((p->mode != HIVE_SEARCH_PUCT && p->mode != HIVE_SEARCH_UCT) || !(p->virtual_loss >= 0.f) || p->max_game_length < 1 ||
+        p->max_game_length > 250)
+        return hive::set_error(HIVE_E_ARG, "hive_search_set_params: unknown mode, negative virtual loss or length cap outside 1..250");
     s->d.prm = *p;
     return HIVE_OK;
 }
@@ -628,6 +757,7 @@ int hive_search_set_roots(HiveSearch *s, const HiveBoard *boards, const HiveHist
     S_TRY(hipSetDevice(s->device));
     hipLaunchKernelGGL(search_reset_kernel, wave_grid(s->d.G), dim3(256), 0, s->stream, s->d, boards, hist, active);
     S_TRY(hipGetLastError());
+    s->sim = 0;                 // simulations are numbered inside one search: part of the noise key (hive_search_set_game_ids)
     return HIVE_OK;
 }
 
@@ -657,8 +787,7 @@ int hive_search_policy(HiveSearch *s, float *policy, int32_t *action, int32_t *s
 {
     if (!s || !action) return hive::set_error(HIVE_E_ARG, "null argument");
     S_TRY(hipSetDevice(s->device));
-    hipLaunchKernelGGL(search_policy_kernel, wave_grid(s->d.G), dim3(256), 0, s->stream, s->d, s->sim++, policy, action, sum_n,
-                       selfplay);
+    hipLaunchKernelGGL(search_policy_kernel, wave_grid(s->d.G), dim3(256), 0, s->stream, s->d, policy, action, sum_n, selfplay);
     S_TRY(hipGetLastError());
     return HIVE_OK;
 }
@@ -683,6 +812,42 @@ int hive_search_node_counts(HiveSearch *s, int32_t *counts)
     if (!s || !counts) return hive::set_error(HIVE_E_ARG, "null argument");
     S_TRY(hipSetDevice(s->device));
     S_TRY(hipMemcpyAsync(counts, s->d.n_nodes, sizeof(int32_t) * s->d.G, hipMemcpyDeviceToDevice, s->stream));
+    return HIVE_OK;
+}
+
+int hive_search_set_game_ids(HiveSearch *s, const int64_t *ids)
+{
+    if (!s || !ids) return hive::set_error(HIVE_E_ARG, "null argument");
+    S_TRY(hipSetDevice(s->device));
+    S_TRY(hipMemcpyAsync(s->d.game_id, ids, sizeof(long long) * (size_t)s->d.G, hipMemcpyDeviceToDevice, s->stream));
+    return HIVE_OK;
+}
+
+int hive_search_root_stats(HiveSearch *s, float *visits, float *total_value, float *priors)
+{
+    if (!s) return hive::set_error(HIVE_E_ARG, "null handle");
+    S_TRY(hipSetDevice(s->device));
+    hipLaunchKernelGGL(search_root_stats_kernel, wave_grid(s->d.G), dim3(256), 0, s->stream, s->d, visits, total_value, priors);
+    S_TRY(hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_search_leaf_histogram(HiveSearch *s, int32_t *hist)
+{
+    if (!s || !hist) return hive::set_error(HIVE_E_ARG, "null argument");
+    S_TRY(hipSetDevice(s->device));
+    S_TRY(hipMemcpyAsync(hist, s->d.kind_hist, sizeof(int32_t) * (size_t)s->d.G * 8, hipMemcpyDeviceToDevice, s->stream));
+    return HIVE_OK;
+}
+
+int hive_search_sample_noise(uint64_t seed, int64_t first_game, int turn, float alpha, int k, int draws, const float *prior,
+                             float eps, float *out, void *stream)
+{
+    if (!out || k < 1 || k > HIVE_EDGE_CAP || draws < 1 || !(alpha > 0.f) || turn < 0 || turn > 255)
+        return hive::set_error(HIVE_E_ARG, "hive_search_sample_noise: bad argument");
+    hipLaunchKernelGGL(search_noise_kernel, wave_grid(draws), dim3(256), 0, (hipStream_t)stream, (unsigned long long)seed,
+                       (long long)first_game, (unsigned)turn, alpha, k, draws, prior, eps, out);
+    S_TRY(hipGetLastError());
     return HIVE_OK;
 }
 

@@ -29,6 +29,19 @@ def shard(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def game_id_stream(rank, world, total=None):
+    """Global game indices rank `rank` of `world` plays.
+
+    total given: the contiguous shard [rank * total / world, (rank + 1) * total / world) of games 0 .. total-1, so the
+    set of games a run plays -- and, the noise being keyed on the game index, every one of their records -- is the
+    same for any number of GPUs.  total None (open-ended runs, bench.py): rank, rank + world, rank + 2 world, ..."""
+    import itertools
+    if total is None:
+        return itertools.count(rank, world)
+    lo, hi = shard(total, rank, world)
+    return iter(range(lo, hi))
+
+
 def _reduce(x, op, device):
     t = torch.tensor([float(x)], dtype=torch.float64, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:

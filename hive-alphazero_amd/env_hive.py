@@ -10,7 +10,9 @@ so copy.deepcopy (solo_play.py:158, MCTS_chess.py:104) is a 448-byte copy.
 For thousands of concurrent games use hive_alphazero_amd.batch.BoardBatch (same kernels, no
 per-call host round trip); this class is the single-game API surface.
 """
+import contextlib
 import copy
+import threading
 
 import numpy as np
 import torch
@@ -51,26 +53,45 @@ class _State:
         return 0 if self.turn % 2 == 1 else 1
 
 
-class _Engine:
-    """One shared single-board HBM slot per device: import record -> kernels -> export."""
+class _EnginePool:
+    """Single-board HBM slots of one device.  A GamePlay call borrows a slot for its load -> kernels -> store
+    sequence and hands it back, so concurrent callers (the reference searches with a ThreadPoolExecutor of
+    SEARCH_THREADS = 32 workers, solo_play.py:153-165) never share a slot: a C-ABI handle is not thread-safe
+    (include/hive_abi.h), distinct handles are independent.  At most as many slots exist as callers ever overlapped."""
     _inst = {}
+    _inst_lock = threading.Lock()
 
     @classmethod
     def get(cls, device=None):
         dev = torch.cuda.current_device() if device is None else device
-        if dev not in cls._inst:
-            cls._inst[dev] = cls(dev)
-        return cls._inst[dev]
+        with cls._inst_lock:
+            if dev not in cls._inst:
+                cls._inst[dev] = cls(dev)
+            return cls._inst[dev]
 
     def __init__(self, dev):
-        self.batch = BoardBatch(1, dev)
+        self.dev = dev
+        self._free = []
+        self._lock = threading.Lock()
+        self.created = 0
 
-    def load(self, rec, hist):
-        self.batch.import_state(rec.reshape(1, 64), hist.reshape(1, 384))
+    @contextlib.contextmanager
+    def slot(self):
+        with self._lock:
+            b = self._free.pop() if self._free else None
+            if b is None:
+                self.created += 1
+        if b is None:
+            b = BoardBatch(1, self.dev)
+        try:
+            yield b
+        finally:
+            with self._lock:
+                self._free.append(b)
 
-    def store(self):
-        b, h = self.batch.export_state()
-        return b.cpu().numpy().reshape(64).copy(), h.cpu().numpy().reshape(384).copy()
+
+def _host(t):
+    return t.cpu().numpy()
 
 
 class GamePlay:
@@ -82,15 +103,23 @@ class GamePlay:
         self.new_game()
 
     # ------------------------------------------------------------------ state plumbing
-    def _eng(self):
-        return _Engine.get(self._device)
+    def _slot(self):
+        return _EnginePool.get(self._device).slot()
 
-    def _refresh(self):
-        """Recompute what the reference recomputes at the end of move(): legal ids (+ lazily planes)."""
-        eng = self._eng()
-        eng.load(self._rec, self._hist)
-        mask, _, _ = eng.batch.legal()
-        self.encoded_action = packing.mask_to_actions(mask.cpu().numpy().view(np.uint32)[0])
+    def _advance(self, action):
+        """load -> [step] -> legal -> store in ONE borrowed slot: what the reference recomputes at the end of move()
+        (env_hive.py:169-171: encoded_action; the planes are built lazily)."""
+        with self._slot() as b:
+            if action is None:
+                b.reset()
+            else:
+                b.import_state(self._rec.reshape(1, 64), self._hist.reshape(1, 384))
+                b.step(np.array([int(action)], dtype=np.int32), sync=True)       # refuses an illegal action (HiveError)
+            mask, _, _ = b.legal()
+            rec, hist = b.export_state()
+            mask, rec, hist = _host(mask), _host(rec), _host(hist)
+        self._rec, self._hist = rec.reshape(64).copy(), hist.reshape(384).copy()
+        self.encoded_action = packing.mask_to_actions(mask.view(np.uint32)[0])
         self._planes = None
         st = packing.unpack_boards(self._rec)
         self._pos, self._lvl = st["pos"][0], st["lvl"][0]
@@ -98,10 +127,7 @@ class GamePlay:
 
     def new_game(self):                      # env_hive.py:61-97
         self.state = _State()
-        eng = self._eng()
-        eng.batch.reset()
-        self._rec, self._hist = eng.store()
-        self._refresh()
+        self._advance(None)
         self.state_key = "." * 144 + "0"
 
     @property
@@ -139,22 +165,18 @@ class GamePlay:
 
     # ------------------------------------------------------------------ reference API
     def game_is_over(self):                  # env_hive.py:58-59, move_checker.py:140-165
-        eng = self._eng()
-        eng.load(self._rec, self._hist)
-        over, winner = eng.batch.terminal()
-        w = int(winner.item())
+        with self._slot() as b:
+            b.import_state(self._rec.reshape(1, 64), self._hist.reshape(1, 384))
+            over, winner = b.terminal()
+            over, w = bool(over.item()), int(winner.item())
         if w == 1:
             self.state.winner = PIECE_WHITE
         elif w == 2:
             self.state.winner = PIECE_BLACK
-        return bool(over.item())
+        return over
 
     def move(self, move, with_skip=False):   # env_hive.py:99-171
-        eng = self._eng()
-        eng.load(self._rec, self._hist)
-        eng.batch.step(np.array([int(move)], dtype=np.int32), sync=True)
-        self._rec, self._hist = eng.store()
-        self._refresh()
+        self._advance(move)
         if int(move) == -1:
             self.state_key = self.state_key[:-1] + str(self.state.player())
         else:
@@ -164,11 +186,7 @@ class GamePlay:
         return self.encoded_action
 
     def skip_turn(self):                     # env_hive.py:493-496 (state_key is NOT updated there)
-        eng = self._eng()
-        eng.load(self._rec, self._hist)
-        eng.batch.step(np.array([-1], dtype=np.int32), sync=True)
-        self._rec, self._hist = eng.store()
-        self._refresh()
+        self._advance(-1)
 
     def encode_board(self, player="N"):      # env_hive.py:306-318
         mover = "W" if self.state.player() == 0 else "B"
@@ -177,9 +195,9 @@ class GamePlay:
         if player != mover:
             raise KeyError(player)           # state_final only holds the mover's planes
         if self._planes is None:
-            eng = self._eng()
-            eng.load(self._rec, self._hist)
-            self._planes = eng.batch.encode(torch.float32, "hwc").cpu().numpy()[0].astype(np.float64)
+            with self._slot() as b:
+                b.import_state(self._rec.reshape(1, 64), self._hist.reshape(1, 384))
+                self._planes = b.encode(torch.float32, "hwc").cpu().numpy()[0].astype(np.float64)
         return self._planes
 
     def turn(self):

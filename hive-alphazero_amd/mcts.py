@@ -20,9 +20,14 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+PUCT, UCT = 0, 1           # HiveSearchMode (include/hive_search.h)
+LEAF_KINDS = ("unused", "root_evaluated", "expanded_evaluated", "known_finished_game", "collision", "length_cap",
+              "new_finished_or_capped", "already_created_in_flight")
+
+
 class _Params(ctypes.Structure):
     _fields_ = [("c_puct", ctypes.c_float), ("noise_eps", ctypes.c_float), ("dirichlet_alpha", ctypes.c_float),
-                ("max_game_length", ctypes.c_int32)]
+                ("max_game_length", ctypes.c_int32), ("mode", ctypes.c_int32), ("virtual_loss", ctypes.c_float)]
 
 
 class TreeSearch:
@@ -31,7 +36,10 @@ class TreeSearch:
     evaluator(planes[B,12,12,56]) -> (p fp32 [B,1584] softmax, v fp32 [B])."""
 
     def __init__(self, games, sims, evaluator, device=None, slots=1, seed=0, plane_dtype=torch.bfloat16,
-                 c_puct=0.7, noise_eps=0.25, dirichlet_alpha=0.3, max_nodes=None, transpositions=True):
+                 c_puct=0.7, noise_eps=0.25, dirichlet_alpha=0.3, max_nodes=None, transpositions=True, mode=PUCT,
+                 virtual_loss=None, max_game_length=None):
+        """mode = PUCT: woker/solo_play.py::HivePlayer; mode = UCT: alpha_zero/MCTS_chess.py::UCT_search (plain tree, no
+        noise, no length cap; with one slot the virtual loss is 0 so that W sums exactly like the sequential reference)."""
         L = load()
         if L.hive_device_count() <= 0 or not torch.cuda.is_available():
             raise _lib.HiveError(-2, "no HIP device visible: hive_alphazero_amd has no CPU path")
@@ -41,7 +49,15 @@ class TreeSearch:
         self.max_nodes = max_nodes or (sims + slots + 2)
         self._h = ctypes.c_void_p()
         check(L.hive_search_create(games, self.max_nodes, slots, self.device.index, seed, ctypes.byref(self._h)))
-        prm = _Params(c_puct, noise_eps, dirichlet_alpha, MAX_GAME_LENGTH)
+        self.mode = mode
+        if mode == UCT:
+            noise_eps, transpositions = 0.0, False
+            if virtual_loss is None:
+                virtual_loss = 0.0 if slots == 1 else 1.0
+            if max_game_length is None:
+                max_game_length = 250
+        prm = _Params(c_puct, noise_eps, dirichlet_alpha, MAX_GAME_LENGTH if max_game_length is None else max_game_length,
+                      mode, 1.0 if virtual_loss is None else virtual_loss)
         check(L.hive_search_set_params(self._h, ctypes.byref(prm)))
         # the reference's tree is a dict keyed by state_key: positions reached by two move orders share one entry
         check(L.hive_search_set_transpositions(self._h, 1 if transpositions else 0))
@@ -107,6 +123,27 @@ class TreeSearch:
         check(L.hive_search_policy(self._h, _p(self.policy), _p(self.action), _p(self.sum_n), 1 if selfplay else 0))
         return self.action, self.policy, self.sum_n
 
+    def set_game_ids(self, ids):
+        """Global game index per tree (int64[games]): the only per-game key of the noise streams (hive_search.h)."""
+        ids = torch.as_tensor(ids, dtype=torch.int64, device=self.device).contiguous()
+        assert ids.numel() == self.games
+        self._stream()
+        check(self.L.hive_search_set_game_ids(self._h, _p(ids)))
+
+    def root_stats(self):
+        """(visits, total_value, priors) fp32[games,1584]: the root's UCTNode arrays (MCTS_chess.py:33-35)."""
+        out = [torch.empty((self.games, 1584), dtype=torch.float32, device=self.device) for _ in range(3)]
+        self._stream()
+        check(self.L.hive_search_root_stats(self._h, _p(out[0]), _p(out[1]), _p(out[2])))
+        return out
+
+    def leaf_histogram(self):
+        """int32[games,8] leaves by kind since create (LEAF_KINDS)."""
+        out = torch.zeros((self.games, 8), dtype=torch.int32, device=self.device)
+        self._stream()
+        check(self.L.hive_search_leaf_histogram(self._h, _p(out)))
+        return out
+
     def node_counts(self):
         out = torch.zeros((self.games,), dtype=torch.int32, device=self.device)
         self._stream()
@@ -124,12 +161,22 @@ class TreeSearch:
 class SelfPlay:
     """`games` self-play games advanced ply by ply (woker/self_play.py:116-193 for every game at once):
     search -> move selection (self-play noise on turns 1..6) -> env step; finished games (queen
-    surrounded or turn >= 55) are scored and replaced by fresh ones.  Records per ply: the packed
+    surrounded or turn >= 55) are scored and their slot takes the next game id.  Records per ply: the packed
     56-bit-per-cell features of the position, the visit policy and the mover; the value is filled
-    in when the game ends (draw or length cap => -1 for both sides, self_play.py:188-189)."""
+    in when the game ends (draw or length cap => -1 for both sides, self_play.py:188-189).
+
+    Game ids: `game_ids` is an iterator of GLOBAL game indices this engine may play (default 0, 1, 2, ...; a
+    multi-GPU run hands every rank its own shard, dist.game_id_stream).  All randomness of game i -- root noise,
+    move resampling -- is keyed on (seed, i, turn, simulation), so its record does not depend on the slot, batch
+    size, process or GPU it ran on.  When the iterator is exhausted a finishing slot goes idle.
+
+    Finished games pile up in `finished_games` as (value_white, plies, game_id) until the caller takes them with
+    `drain_finished()`; more than `max_finished_kept` undrained games are dropped and counted (`dropped_games`,
+    one warning)."""
 
     def __init__(self, games, sims, evaluator, device=None, slots=1, seed=0, plane_dtype=torch.bfloat16,
-                 keep_records=True):
+                 keep_records=True, game_ids=None, max_finished_kept=1024, report_every=0, log=print):
+        import itertools
         from .batch import BoardBatch
         self.games, self.sims = games, sims
         self.env = BoardBatch(games, device)
@@ -139,20 +186,27 @@ class SelfPlay:
         self.finished = 0
         self.white_wins = self.black_wins = self.draws = 0
         self.plies = 0
-        self.finished_lengths = []
-        self.records = []            # (features int64[games,144], policy fp32[games,1584], mover int8[games], game_id)
-        self.game_id = torch.arange(games, device=self.device)
-        self._next_id = games
-        # per running game: list of (packed features uint64[144], history words uint32[4,2,6] + length, turn,
-        # visit policy float32[1584], mover) -- turned into the reference's rows when the game ends
-        self._log = []               # per ply: host arrays of every game (features, history, records, policy, moved?)
-        self._start_ply = [0] * games   # index into the ply counter at which the game in each slot started
-        self.finished_games = []     # list of (value_white, plies) for the first max_finished_kept finished games
-        self.max_finished_kept = 64
+        self.finished_lengths = []   # mean final turn number of the games retired at one ply (bench statistics)
+        self.finished_turns = []     # final turn number of every finished game
+        self.records = []            # last 8 plies on the device: (features int64[games,144], policy, mover, game_id)
+        self._ids = iter(game_ids) if game_ids is not None else itertools.count(0)
+        first = [next(self._ids, -1) for _ in range(games)]
+        self.game_id = torch.tensor(first, dtype=torch.int64, device=self.device)
+        self.active = (self.game_id >= 0).to(torch.int8)
+        self.search.set_game_ids(torch.clamp(self.game_id, min=0))
+        # host copies of every ply still needed by a running game (features, history, policy, records, moved?)
+        self._log = []
+        self._start_ply = [0] * games   # ply counter at which the game in each slot started
+        self._unlogged = [False] * games   # opening plies of this slot's game were played outside play_ply (stagger)
+        self.finished_games = []
+        self.max_finished_kept = max_finished_kept
+        self.dropped_games = self.unrecorded_games = 0
+        self.report_every, self._log_fn, self._reported = report_every, log, 0
 
     def stagger(self, seed=0):
         """Spread the games over plies 0..53 with uniformly random legal moves so that a timed window
-        sees the steady state."""
+        sees the steady state.  Those opening plies are not searched and not logged, so the
+        games they belong to produce no training rows (their [game_len, counter] would be wrong)."""
         from .playout import pick_uniform
         gen = torch.Generator(device=self.device)
         gen.manual_seed(seed)
@@ -161,14 +215,19 @@ class SelfPlay:
             over, _ = self.env.terminal()
             _, count, lst = self.env.legal(want_list=True)
             a = pick_uniform(count, lst, gen)
-            go = (target > ply) & (over == 0)
+            go = (target > ply) & (over == 0) & (self.active != 0)
             self.env.step(torch.where(go, a, torch.full_like(a, -2)), sync=False)
+        self._unlogged = [bool(t > 0) for t in target.cpu().tolist()]
+
+    def running(self):
+        """Number of slots that still hold a game."""
+        return int(self.active.sum().item())
 
     def _retire_finished(self):
         boards, _ = self.env.export_state()
         over, winner = self.env.terminal()
         turn = boards[:, 33].to(torch.int32)
-        done = (over != 0) | (turn >= MAX_GAME_LENGTH)
+        done = ((over != 0) | (turn >= MAX_GAME_LENGTH)) & (self.active != 0)
         nd = int(done.sum().item())
         if nd:
             w = winner[done]
@@ -177,25 +236,64 @@ class SelfPlay:
             self.draws += int((w == 0).sum().item())
             self.finished += nd
             self.finished_lengths.append(turn[done].float().mean().item())
+            self.finished_turns += turn[done].cpu().tolist()
             idx = torch.nonzero(done).view(-1).to(torch.int32)
+            slots = idx.cpu().tolist()
             if self.keep_records:
-                self._close_games(idx.cpu().tolist(), winner.cpu().tolist())
+                self._close_games(slots, winner.cpu().tolist(), self.game_id.cpu().tolist())
+            else:
+                for s in slots:
+                    self._start_ply[s], self._unlogged[s] = self.plies, False
+            fresh = [next(self._ids, -1) for _ in slots]
+            for sl, f in zip(slots, fresh):
+                if f < 0:
+                    self._start_ply[sl] = 1 << 60          # idle from now on: nothing of the log belongs to it
+            self.game_id[idx.long()] = torch.tensor(fresh, dtype=torch.int64, device=self.device)
+            self.active = (self.game_id >= 0).to(torch.int8)
+            self.search.set_game_ids(torch.clamp(self.game_id, min=0))
             self.env.reset(idx)
-            self.game_id[done] = torch.arange(self._next_id, self._next_id + nd, device=self.device)
-            self._next_id += nd
+            self._report()
         return nd
 
-    def _close_games(self, slots, winner):
+    retire_finished = _retire_finished
+
+    def _report(self):
+        """woker/self_play.py:69-75: every `report_every` games -- games so far, mean game length, white's win rate."""
+        if self.report_every and self.finished - self._reported >= self.report_every:
+            self._reported = self.finished - self.finished % self.report_every
+            self._log_fn(f" Total_game {self.finished} ---  Mean_game_len {self.mean_game_length():.2f} ---  "
+                         f"White_Win % {self.white_wins / max(self.finished, 1):.2f} ---  "
+                         f"(white {self.white_wins} black {self.black_wins} draw_or_cap {self.draws})")
+
+    def mean_game_length(self):
+        """Mean number of plies of the finished games (final turn number - 1)."""
+        return (sum(self.finished_turns) / len(self.finished_turns) - 1.0) if self.finished_turns else 0.0
+
+    def _close_games(self, slots, winner, ids):
         """self_play.py:165-191: value_white = +1 / -1 / 0; a draw or the length cap scores -1 for both."""
-        from . import records
+        import warnings
         for s in slots:
             start, self._start_ply[s] = self._start_ply[s], self.plies
+            unlogged, self._unlogged[s] = self._unlogged[s], False
+            if unlogged:
+                self.unrecorded_games += 1
+                continue
             if len(self.finished_games) >= self.max_finished_kept:
+                if self.dropped_games == 0:
+                    warnings.warn(f"SelfPlay: more than {self.max_finished_kept} finished games are waiting; call "
+                                  "drain_finished() -- further games are dropped (dropped_games counts them)")
+                self.dropped_games += 1
                 continue
             plies = [self.ply_record(e, s) for e in self._log if e["ply"] >= start and e["moved"][s]]
             if plies:
                 vw = 1 if winner[s] == 1 else (-1 if winner[s] == 2 else 0)
-                self.finished_games.append((vw, plies))
+                self.finished_games.append((vw, plies, ids[s]))
+
+    def drain_finished(self):
+        """Take (and forget) every finished game collected so far: list of (value_white, plies, game_id);
+        `game_rows(entry)` turns one into the reference's rows."""
+        out, self.finished_games = self.finished_games, []
+        return out
 
     @staticmethod
     def ply_record(entry, g):
@@ -210,21 +308,27 @@ class SelfPlay:
     def last_ply_record(self, g):
         return self.ply_record(self._log[-1], g) if self._log and self._log[-1]["moved"][g] else None
 
-    def finished_game_rows(self, k):
-        """The k-th kept finished game as the reference's JSON rows [state, policy, value, [game_len, counter]]."""
+    @staticmethod
+    def game_rows(entry):
+        """One finished game as the reference's JSON rows [state, policy, value, [game_len, counter]]."""
         from . import records
-        vw, plies = self.finished_games[k]
+        vw, plies = entry[0], entry[1]
         expanded = []
         for words, hist, hlen, turn, policy, mover in plies:
             hp = records.history_planes(hist, hlen)
             expanded.append((records.unpack_features(words, turn, hp), policy, "W" if mover == 0 else "B"))
         return records.game_entries(expanded, vw)
 
+    def finished_game_rows(self, k):
+        """The k-th waiting finished game as the reference's rows."""
+        return self.game_rows(self.finished_games[k])
+
     def play_ply(self):
         """One move for every game.  Returns the number of games that finished before this move."""
         nd = self._retire_finished()
         boards, hist = self.env.export_state()
-        action, policy, sum_n = self.search.search(boards, hist, selfplay=True, keep_root_planes=self.keep_records)
+        action, policy, sum_n = self.search.search(boards, hist, active=self.active, selfplay=True,
+                                                   keep_root_planes=self.keep_records)
         if self.keep_records:
             mover = (1 - (boards[:, 33] & 1)).to(torch.int8)
             self.records.append((self.search.root_planes.view(self.games, 144), policy.clone(), mover, self.game_id.clone()))
@@ -240,13 +344,19 @@ class SelfPlay:
                 "hist": hist.cpu().numpy().view("uint32").reshape(self.games, 2, 4, 2, 6),
                 "moved": (action != -2).cpu().numpy(),
             })
-            if len(self._log) > MAX_GAME_LENGTH + 1:
+            oldest = min(self._start_ply)
+            while self._log and self._log[0]["ply"] < oldest:
                 self._log.pop(0)
         # the env re-derives the legal masks and refuses anything not in them: the search's edges come
         # from the same kernels, so illegal_count() must stay 0 (asserted by the tests)
         self.env.step(action, sync=False)
         self.plies += 1
         return nd
+
+    def leaf_histogram(self):
+        """{kind: count} over every simulation since create (TreeSearch.leaf_histogram summed over the games)."""
+        h = self.search.leaf_histogram().sum(0).cpu().tolist()
+        return {k: int(v) for k, v in zip(LEAF_KINDS, h) if k != "unused"}
 
     def close(self):
         self.search.close()

@@ -1,74 +1,142 @@
-"""self_play_buffer: mirror of the reference's woker/self_play.py::self_play_buffer (:116-193), the
-drop-in caller of this package's GamePlay / HivePlayer.  Line 149 of the reference indexes a list
-with a list (TypeError on move 1); the working form is woker/self_play_with_train.py:179 and is
-what is used here.  One game per call, sequential search -- the reference's own process model; the
-throughput path is hive_alphazero_amd.mcts.SelfPlay.
+"""SelfPlayWorker: the self-play producer of woker/self_play.py (:35-112) on a node of MI355Xs.
+
+The reference keeps 120 games in flight in a ProcessPoolExecutor of 60 single-game workers that all talk to ONE
+network thread through pipes (self_play.py:37-75).  Here one process owns one GPU (`HIP_VISIBLE_DEVICES`, set before
+the child touches HIP) and plays `games_per_gpu` games in lock step entirely on that GPU -- env, tree search and
+network (mcts.SelfPlay) -- so there is no cross-process inference traffic and no inter-GPU traffic at all.  The
+parent only gathers finished games from a queue, prints the reference's progress line every 10 games
+(self_play.py:69-75), and flushes `play_<ts>.json` files of the reference's rows every `games_per_file` games
+(self_play.py:64-67,100-112).
+
+Games are numbered globally: with `total_games` = T the ranks own contiguous shards of 0 .. T-1 (dist.game_id_stream)
+and every random draw of game i is keyed on (seed, i, turn, simulation).  A game's record therefore does not depend
+on how many GPUs took part, and `results` (game id -> (value_white, rows)) is identical for 1, 2 or 8 GPUs.
 """
-from copy import deepcopy
+import multiprocessing as mp
+import os
+import queue as queue_mod
+import time
 
-import numpy as np
-
-from .config import MAX_GAME_LENGTH, PIECE_BLACK, PIECE_WHITE
-from .solo_play import HivePlayer
+from . import records
+from .dist import game_id_stream
 
 
-def self_play_buffer(cur, make_env=None, simulations=None):
-    """cur: list of pipe lists (one popped per game, self_play.py:118).  Returns (data, [value_white])."""
-    if make_env is None:
-        from .env_hive import GamePlay
-        board = GamePlay(HEIGHT_MAP=1050, WIDTH_MAP=900)
-    else:
-        board = make_env()
-    pipes = cur.pop()
-    white, black = HivePlayer(pipes=pipes), HivePlayer(pipes=pipes)
-    if simulations is not None:
-        white.simulation_num_per_move = black.simulation_num_per_move = simulations
-    state_policy_player = []
-    black_count = white_count = 0
-    e = 0.7
-    while not board.game_is_over():
-        if board.state.player() == 0:
-            action, policy = white.action(board)
-            player = "W"
-            white_count += 1
-            counter = white_count
-        else:
-            action, policy = black.action(board)
-            player = "B"
-            black_count += 1
-            counter = black_count
-        if board.state.turn <= 2:
-            action = np.random.choice(board.actions())
-        policy = policy[0]
-        error = e - int(board.state.turn + 1) / 2 * 0.15
-        actions = board.actions()
-        if error >= 0.1 and len(actions) != 0:
-            p = np.array(policy)[actions]
-            noise = np.random.dirichlet([0.5] * len(actions))
-            p = (1 - error) * np.array(p) + error * noise
-            p /= p.sum()
-            action = np.random.choice(board.actions(), p=p)
-        state = board.encode_board(player)
-        state_policy_player.append([state.tolist(), policy, player, counter])
-        board.move(int(action))
-        if board.state.turn >= MAX_GAME_LENGTH:
-            break
+def _game_worker(rank, world, cfg, out):
+    """One GPU's producer (child process; the parent exported HIP_VISIBLE_DEVICES = this rank's GPU for it)."""
+    import torch
+    from . import mcts
+    from .alpha_net import ChessNet, InferenceNet
+    try:
+        torch.manual_seed(cfg["net_seed"])
+        net = ChessNet()
+        if cfg.get("checkpoint"):
+            # the reference's checkpoints are {'state_dict': ...} (self_play.py:92-96); tensors only, nothing executed
+            net.load_state_dict(torch.load(cfg["checkpoint"], map_location="cpu", weights_only=True)["state_dict"])
+        evaluator = InferenceNet(net.cuda().eval(), dtype=torch.bfloat16)
+        ids = game_id_stream(rank, world, cfg["total_games"])
+        sp = mcts.SelfPlay(cfg["games_per_gpu"], cfg["sims"], evaluator, device=0, slots=cfg["slots"], seed=cfg["seed"],
+                           game_ids=ids)
+        while True:
+            sp.play_ply()
+            for entry in sp.drain_finished():
+                out.put(("game", rank, entry[2], entry[0], mcts.SelfPlay.game_rows(entry)))
+            if sp.running() == 0:
+                break
+        illegal, leaves = sp.env.illegal_count(), sp.leaf_histogram()
+        sp.close()
+        out.put(("done", rank, sp.finished, illegal, leaves))
+    except BaseException as exc:                 # the parent must not wait for a rank that died
+        out.put(("error", rank, repr(exc), 0, None))
+        raise
 
-    value_white = 0
-    if board.game_is_over():
-        if board.state.winner == PIECE_WHITE:
-            value_white = 1
-        elif board.state.winner == PIECE_BLACK:
-            value_white = -1
-    white.finish_game(value_white)
-    black.finish_game(-value_white)
 
-    data = []
-    for state, policy, player, counter in state_policy_player:
-        value = value_white if player == "W" else -value_white
-        game_lens = white_count if player == "W" else black_count
-        if value_white == 0:
-            value = -1
-        data.append([state, policy, value, [game_lens, counter]])
-    cur.append(pipes)
-    return data, [value_white]
+class SelfPlayWorker:
+    def __init__(self, total_games, games_per_gpu=1024, sims=50, gpus=None, seed=0, net_seed=0, checkpoint=None, slots=1,
+                 datapath="../dataSelf", games_per_file=100, report_every=10, worker=_game_worker, log=print):
+        self.cfg = {"total_games": int(total_games), "games_per_gpu": int(games_per_gpu), "sims": int(sims), "seed": int(seed),
+                    "net_seed": int(net_seed), "checkpoint": checkpoint, "slots": int(slots)}
+        if gpus is None:
+            import torch
+            gpus = list(range(torch.cuda.device_count()))      # counting devices does not initialise HIP
+        self.gpus = [int(g) for g in gpus]
+        if not self.gpus:
+            raise RuntimeError("SelfPlayWorker: no GPU given / visible (there is no CPU path)")
+        self.datapath, self.games_per_file, self.report_every = datapath, games_per_file, report_every
+        self._worker, self._log = worker, log
+        self.results = {}            # game id -> (value_white, rows)
+        self.win_lose, self.game_lens, self.files = [], [], []
+        self.buffer = []
+        self.leaf_kinds = {}         # leaves of every simulation by kind, summed over the ranks (mcts.LEAF_KINDS)
+
+    # ---------------------------------------------------------------- parent side
+    def _spawn(self, out):
+        ctx = mp.get_context("spawn")
+        procs = []
+        world = len(self.gpus)
+        saved = os.environ.get("HIP_VISIBLE_DEVICES")
+        try:
+            for rank, gpu in enumerate(self.gpus):
+                os.environ["HIP_VISIBLE_DEVICES"] = str(gpu)    # inherited at spawn: set before the child's first HIP call
+                p = ctx.Process(target=self._worker, args=(rank, world, self.cfg, out), daemon=True)
+                p.start()
+                procs.append(p)
+        finally:
+            if saved is None:
+                os.environ.pop("HIP_VISIBLE_DEVICES", None)
+            else:
+                os.environ["HIP_VISIBLE_DEVICES"] = saved
+        return procs
+
+    def _take(self, game_id, value_white, rows):
+        self.results[game_id] = (value_white, rows)
+        self.win_lose.append(value_white)
+        self.game_lens.append(len(rows))
+        self.buffer += rows
+        n = len(self.win_lose)
+        if self.games_per_file and n % self.games_per_file == 0:
+            self.flush_buffer()
+        if self.report_every and n % self.report_every == 0:
+            wins = sum(1 for v in self.win_lose if v == 1)
+            self._log(f" Total_game {n} ---  Mean_game_len {sum(self.game_lens) / n:.2f} ---  "
+                      f"White_Win % {wins / n:.2f} --- ")
+
+    def flush_buffer(self):
+        if self.buffer and self.datapath:
+            self.files.append(records.flush_buffer(self.buffer, self.datapath))
+        self.buffer = []
+
+    def start(self, timeout_s=None):
+        """Play games 0 .. total_games-1; returns {game id: (value_white, rows)} ordered by game id."""
+        ctx = mp.get_context("spawn")
+        out = ctx.Queue()
+        procs = self._spawn(out)
+        pending, t0 = set(range(len(procs))), time.time()
+        try:
+            while pending:
+                try:
+                    msg = out.get(timeout=1.0)
+                except queue_mod.Empty:
+                    dead = [r for r in pending if not procs[r].is_alive()]
+                    if dead and out.empty():
+                        raise RuntimeError(f"self-play rank(s) {dead} exited without reporting")
+                    if timeout_s is not None and time.time() - t0 > timeout_s:
+                        raise TimeoutError("SelfPlayWorker.start: timeout")
+                    continue
+                if msg[0] == "game":
+                    self._take(msg[2], msg[3], msg[4])
+                elif msg[0] == "done":
+                    pending.discard(msg[1])
+                    for kind, count in (msg[4] or {}).items():
+                        self.leaf_kinds[kind] = self.leaf_kinds.get(kind, 0) + count
+                    if msg[3]:
+                        raise RuntimeError(f"rank {msg[1]}: the env refused {msg[3]} moves of the search")
+                else:
+                    raise RuntimeError(f"self-play rank {msg[1]} failed: {msg[2]}")
+        finally:
+            for p in procs:
+                p.join(timeout=10)
+                if p.is_alive():
+                    p.terminate()
+        self.flush_buffer()
+        self.results = dict(sorted(self.results.items()))
+        return self.results

@@ -39,11 +39,25 @@ extern "C" {
 
 typedef struct HiveSearch HiveSearch;
 
+/* Which of the reference's two searches the kernels run. */
+typedef enum {
+    HIVE_SEARCH_PUCT = 0,  /* woker/solo_play.py::HivePlayer (:167-374): q = w/n, u = c_puct p sqrt(sum_n + 1)/(1 + n), priors masked
+                              and renormalised, root Dirichlet noise per simulation, draw sentinel, length cap, state_key merging */
+    HIVE_SEARCH_UCT = 1    /* alpha_zero/MCTS_chess.py::UCTNode/UCT_search (:52-151): Q = W/(1 + N), U = sqrt(N_node) |P|/(1 + N)
+                              (c = 1), illegal priors zeroed WITHOUT renormalisation, no noise, plain tree, the backup adds
+                              +v to edges played by white and -v to edges played by black (:111-119), a finished game or a
+                              position without legal moves is re-evaluated by the network on every visit (:144-146, :87-88),
+                              no length cap.  All score arithmetic in fp32 with the reference's operation order. */
+} HiveSearchMode;
+
 typedef struct HiveSearchParams {
     float c_puct;          /* solo_play.py:26   0.7  */
     float noise_eps;       /* solo_play.py:29   0.25 */
     float dirichlet_alpha; /* solo_play.py:28   0.3  */
     int32_t max_game_length; /* hive_engine/config.py:22  55 */
+    int32_t mode;          /* HiveSearchMode */
+    float virtual_loss;    /* solo_play.py:30   1 (n += 1, w -= virtual_loss while a simulation is in flight).  UCT with one
+                              slot: 0, which keeps W bit-identical to the reference's sequential sums */
 } HiveSearchParams;
 
 int hive_search_create(int games, int max_nodes, int slots, int device, uint64_t seed, HiveSearch **out);
@@ -81,6 +95,31 @@ int hive_search_transposition_hits(HiveSearch *s, int32_t *hits);
 
 /* Statistics for tests: nodes allocated per tree (int32[games]). */
 int hive_search_node_counts(HiveSearch *s, int32_t *counts);
+
+/* Global game index of every tree (device int64[games]; default: 0 .. games-1).  The Dirichlet / resampling streams of
+ * game i are keyed on (seed, ids[i], turn of the root position, simulation number inside the search, slot, edge) and on
+ * nothing else, so a self-play game comes out the same whichever batch slot, process or GPU runs it
+ * (seed = base + global_game_index; woker/self_play.py:37-75 seeds nothing and is not reproducible). */
+int hive_search_set_game_ids(HiveSearch *s, const int64_t *ids);
+
+/* Root statistics as the reference's UCTNode arrays (alpha_zero/MCTS_chess.py:33-35): visits / total_value / priors =
+ * float[games][1584] each (any may be NULL), zero outside the root's edges.  PUCT mode: n, w, p of the root entry
+ * (solo_play.py:51-66). */
+int hive_search_root_stats(HiveSearch *s, float *visits, float *total_value, float *priors);
+
+/* Leaves by kind since create: int32[games][8], every simulation of an active game adds one: [1] root evaluated,
+ * [2] new position evaluated (1 + 2 = the network evaluations the search NEEDED), [3] descent ended in a known finished
+ * game, [4] collision between in-flight slots, [5] descent ended at the length cap, [6] new position that is a finished
+ * game or sits at the length cap (PUCT: its value does not come from the network), [7] new position that another
+ * in-flight slot had already created.  [0] unused. */
+int hive_search_leaf_histogram(HiveSearch *s, int32_t *hist);
+
+/* The search's own noise generator, exposed for statistical tests: draw d (= 0 .. draws-1) is what the root of game id
+ * `first_game + d` would get at (turn, sim 0, slot 0): eta ~ Dirichlet(alpha) over k <= HIVE_EDGE_CAP edges
+ * (solo_play.py:322-323, np.random.dirichlet).  out = float[draws][k]; prior = float[k] or NULL:
+ * out = (1 - eps) prior + eps eta (solo_play.py:323), or eta itself when prior is NULL. */
+int hive_search_sample_noise(uint64_t seed, int64_t first_game, int turn, float alpha, int k, int draws, const float *prior,
+                             float eps, float *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,327 @@
+"""BASELINE-size searches, the production (noise-on) search mode, game-id keyed reproducibility and the façade under the
+reference's default threading -- all through the C ABI on the GPU."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from mcts_stub import StubPipe, stub_predict   # noqa: E402
+
+
+def _host_stub_evaluator(planes):
+    x = planes.float().cpu().numpy()
+    ps, vs = zip(*(stub_predict(x[i]) for i in range(x.shape[0])))
+    return torch.from_numpy(np.stack(ps)).cuda(), torch.tensor(vs, dtype=torch.float32).cuda()
+
+
+def _support_inside_legal(policy, mask):
+    """policy fp32[G,1584] > 0 only where the legal set (uint32[G,66] destination boards) has the bit -- on the device."""
+    a = torch.arange(1584, device=policy.device)
+    cell, slot = a // 11, a % 11
+    word = slot * 6 + (cell // 12) // 2
+    bit = (((cell // 12) & 1) << 4) | (cell % 12)
+    legal = (mask[:, word] >> bit.to(torch.int32)) & 1
+    return bool(((policy > 0) & (legal == 0)).sum().item() == 0), legal
+
+
+@pytest.fixture(scope="module")
+def bf16_net():
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    torch.manual_seed(0)
+    return InferenceNet(ChessNet().cuda().eval(), dtype=torch.bfloat16)
+
+
+def test_config2_1024_games_50_sims_two_plies_and_oracle_lockstep(bf16_net):
+    """BASELINE configs[2] at full size: 1024 games x 50 simulations, random-init network, root noise on.  Two plies from the
+    opening: every simulation accounted for, policy support inside the legal set, no node pool exhausted, nothing refused
+    by the env; the moves of 64 of the games replayed through the CPU oracle in lock step (legal sets after every move)."""
+    from oracle import oracle_py as O
+    from hive_alphazero_amd import mcts, packing
+    G, sims = 1024, 50
+    sp = mcts.SelfPlay(G, sims, bf16_net, seed=11, keep_records=False)
+    oracle_games = [O.OracleGame() for _ in range(64)]
+    for ply in range(2):
+        mask, count, _ = sp.env.legal()
+        sp.play_ply()
+        action, policy, sum_n = sp.search.action, sp.search.policy, sp.search.sum_n
+        assert bool((sum_n == sims - 1).all().item())                   # the first simulation opens the root, no collisions
+        ok, legal = _support_inside_legal(policy, mask)
+        assert ok
+        assert bool((legal.gather(1, action.long().view(-1, 1)) == 1).all().item())
+        assert float((policy.sum(1) - 1).abs().max().item()) < 1e-4
+        nodes = sp.search.node_counts()
+        assert int(nodes.max().item()) <= sims and int(nodes.min().item()) >= 1 and sims < sp.search.max_nodes
+        acts = action[:64].cpu().tolist()
+        after, _, _ = sp.env.legal()
+        m = after[:64].cpu().numpy().view(np.uint32)
+        for i, g in enumerate(oracle_games):
+            assert acts[i] in g.actions()
+            g.move(acts[i])
+            assert packing.mask_to_actions(m[i]) == g.actions(), (ply, i)
+    hist = sp.leaf_histogram()
+    assert hist["root_evaluated"] == 2 * G and sum(hist.values()) == 2 * G * sims and hist["collision"] == 0
+    assert sp.env.illegal_count() == 0
+    sp.close()
+
+
+def test_config4_1024_games_250_sims_four_slots_one_ply(bf16_net):
+    """BASELINE configs[4] at full size: 1024 games x 250 simulations with four leaves in flight per tree (virtual loss),
+    one ply from mid-game positions: visits accounted for (collisions give theirs back), pool never exhausted, legal moves."""
+    from hive_alphazero_amd import batch, mcts, playout
+    G, sims, slots = 1024, 250, 4
+    boards = playout.random_positions(G, seed=31)
+    B = batch.BoardBatch(G)
+    B.import_state(boards)
+    rb, rh = B.export_state()
+    over, _ = B.terminal()
+    mask, count, _ = B.legal()
+    ts = mcts.TreeSearch(G, sims, bf16_net, seed=7, slots=slots)
+    action, policy, sum_n = ts.search(rb, rh)
+    torch.cuda.synchronize()
+    live = (over == 0) & (rb[:, 33] < 55)
+    assert int(live.sum().item()) > 900
+    ok, legal = _support_inside_legal(policy, mask)
+    assert ok
+    has_move = live & (count > 0)
+    assert bool((legal[has_move].gather(1, action[has_move].long().view(-1, 1)) == 1).all().item())
+    assert bool((action[live & (count == 0)] == -1).all().item()) and bool((action[~live] == -2).all().item())
+    hist = ts.leaf_histogram()
+    # every in-flight slot of a live game is one histogram entry; a collision gives its visit back, nothing else is lost
+    assert bool((hist.sum(1)[live] == sims).all().item()) and bool((hist.sum(1)[~live] == 0).all().item())
+    assert bool((sum_n[live] == sims - 1 - hist[live][:, 4]).all().item())
+    assert bool((sum_n[live] > sims // 2).all().item())
+    nodes = ts.node_counts()
+    assert int(nodes.max().item()) <= sims and sims + slots < ts.max_nodes + 1
+    ts.close(); B.close()
+
+
+@pytest.mark.parametrize("alpha,k", [(0.3, 30), (0.5, 50), (0.3, 131)])
+def test_kernel_dirichlet_moments_and_marginal(alpha, k):
+    """The search's own noise generator (Marsaglia-Tsang gammas with an iteration cap, Box-Muller on fast intrinsics;
+    csrc/hive_search.hip) against np.random.dirichlet's law (solo_play.py:322-323, self_play.py:151): 100,000 draws --
+    each sums to 1, every coordinate's mean is 1/k and variance (1/k)(1 - 1/k)/(k alpha + 1) within 5 sigma, and one
+    coordinate's marginal is Beta(alpha, (k - 1) alpha) by a Kolmogorov-Smirnov test."""
+    import ctypes
+    from scipy import stats
+    import hive_alphazero_amd as h
+    L = h.load()
+    draws = 100_000
+    out = torch.empty((draws, k), dtype=torch.float32, device="cuda")
+    rc = L.hive_search_sample_noise(12345, 0, 3, ctypes.c_float(alpha), k, draws, None, ctypes.c_float(0.0),
+                                    ctypes.c_void_p(out.data_ptr()), None)
+    assert rc == 0, L.hive_last_error()
+    torch.cuda.synchronize()
+    x = out.double().cpu().numpy()
+    assert np.abs(x.sum(1) - 1).max() < 1e-5 and x.min() >= 0
+    mean, var = 1.0 / k, (1.0 / k) * (1 - 1.0 / k) / (k * alpha + 1)
+    z_mean = (x.mean(0) - mean) / np.sqrt(var / draws)
+    assert np.abs(z_mean).max() < 5, z_mean
+    # variance of the sample variance from the Beta's fourth central moment
+    a, b = alpha, (k - 1) * alpha
+    m4 = stats.beta(a, b).moment(4) - 4 * mean * stats.beta(a, b).moment(3) + 6 * mean ** 2 * stats.beta(a, b).moment(2) - 3 * mean ** 4
+    z_var = (x.var(0) - var) / np.sqrt((m4 - var ** 2) / draws)
+    assert np.abs(z_var).max() < 5, z_var
+    # off-diagonal covariance -mean^2/(k alpha + 1): one pair
+    cov = np.mean((x[:, 0] - mean) * (x[:, 1] - mean))
+    assert abs(cov + mean * mean / (k * alpha + 1)) < 6 * var / np.sqrt(draws)
+    ks = stats.kstest(x[:, k // 2], stats.beta(a, b).cdf)
+    assert ks.pvalue > 1e-4, ks
+    # different games / turns draw different noise; the same key draws the same
+    again = torch.empty_like(out)
+    L.hive_search_sample_noise(12345, 0, 3, ctypes.c_float(alpha), k, draws, None, ctypes.c_float(0.0),
+                               ctypes.c_void_p(again.data_ptr()), None)
+    other = torch.empty_like(out)
+    L.hive_search_sample_noise(12345, 0, 4, ctypes.c_float(alpha), k, draws, None, ctypes.c_float(0.0),
+                               ctypes.c_void_p(other.data_ptr()), None)
+    torch.cuda.synchronize()
+    assert torch.equal(again, out) and not torch.equal(other, out)
+    assert torch.equal(out[1:], _shifted(L, alpha, k, draws)[:-1])        # draw d of first_game 1 = draw d + 1 of first_game 0
+
+
+def _shifted(L, alpha, k, draws):
+    import ctypes
+    t = torch.empty((draws, k), dtype=torch.float32, device="cuda")
+    L.hive_search_sample_noise(12345, 1, 3, ctypes.c_float(alpha), k, draws, None, ctypes.c_float(0.0),
+                               ctypes.c_void_p(t.data_ptr()), None)
+    torch.cuda.synchronize()
+    return t
+
+
+def test_root_noise_mixing_on_a_fixed_prior():
+    """(1 - eps) p + eps eta with eps = 0.25 on a fixed prior (solo_play.py:323): exactly that combination of the prior
+    and the noise the same key draws alone; still a distribution."""
+    import ctypes
+    import hive_alphazero_amd as h
+    L = h.load()
+    k, draws, eps = 40, 4096, 0.25
+    prior = torch.softmax(torch.randn(k, generator=torch.Generator().manual_seed(0)), 0).cuda()
+    eta = torch.empty((draws, k), dtype=torch.float32, device="cuda")
+    mix = torch.empty_like(eta)
+    args = (99, 1000, 9, ctypes.c_float(0.3), k, draws)
+    assert L.hive_search_sample_noise(*args, None, ctypes.c_float(0.0), ctypes.c_void_p(eta.data_ptr()), None) == 0
+    assert L.hive_search_sample_noise(*args, ctypes.c_void_p(prior.data_ptr()), ctypes.c_float(eps), ctypes.c_void_p(mix.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    want = (1 - eps) * prior.double()[None, :] + eps * eta.double()
+    assert float((mix.double() - want).abs().max().item()) < 1e-7
+    assert float((mix.sum(1) - 1).abs().max().item()) < 1e-5
+
+
+def test_selfplay_move_resampling_frequencies():
+    """self_play.py:139-157 in the kernel (search_policy_kernel): on turn 3 the move is drawn from
+    (1 - e) pi + e Dirichlet(0.5), e = 0.7 - 0.15 * 2 = 0.4.  8192 games searched from the SAME position with the root
+    noise off (so pi is the same for all) differ only in their game id: the frequencies of the chosen moves must follow
+    E[(1 - e) pi + e eta] = (1 - e) pi + e / k (chi-square, k - 1 degrees of freedom)."""
+    from scipy import stats
+    from hive_alphazero_amd import batch, mcts
+    from hive_alphazero_amd.env_hive import GamePlay
+    g = GamePlay(1050, 900)
+    for _ in range(2):                                     # one piece each: turn 3, the first turn with a real choice
+        g.move(g.actions()[0])
+    assert g.state.turn == 3
+    G, sims = 8192, 12
+    rb = torch.from_numpy(np.repeat(g._rec.reshape(1, 64), G, 0)).cuda()
+    rh = torch.from_numpy(np.repeat(g._hist.reshape(1, 384), G, 0)).cuda()
+
+    def flat_eval(planes):
+        B = planes.shape[0]
+        return torch.full((B, 1584), 1.0 / 1584, device="cuda"), torch.zeros((B,), device="cuda")
+
+    ts = mcts.TreeSearch(G, sims, flat_eval, plane_dtype=torch.float32, seed=5, noise_eps=0.0)
+    action, policy, _ = ts.search(rb, rh, selfplay=True)
+    torch.cuda.synchronize()
+    pi = policy[0].double().cpu().numpy()
+    assert bool((policy == policy[0]).all().item())
+    legal = g.actions()
+    k = len(legal)
+    e = 0.7 - int(3 + 1) / 2 * 0.15
+    expect = (1 - e) * pi[legal] + e / k
+    got = np.bincount(action.cpu().numpy(), minlength=1584)[legal]
+    assert got.sum() == G                                   # never an action outside the legal set
+    chi = stats.chisquare(got, expect / expect.sum() * G)
+    assert chi.pvalue > 1e-4, (chi, k)
+    # and without the self-play flag every game plays the argmax
+    a2, _, _ = ts.search(rb, rh, selfplay=False)
+    assert bool((a2 == a2[0]).all().item())
+    ts.close()
+
+
+def test_game_records_do_not_depend_on_batch_slot_or_size():
+    """game i's noise is keyed on (seed, i, turn, simulation) only.  Games 132..163 played as slots 32..63 of a
+    64-game engine and as slots 0..31 of a 32-game engine (root noise ON, self-play resampling ON) choose the same moves
+    with the same visit policies at every ply -- so a game's record is the same on 1 GPU or 8."""
+    from hive_alphazero_amd import mcts
+    runs = {}
+    for games, first in ((64, 100), (32, 132)):
+        sp = mcts.SelfPlay(games, 10, _host_stub_evaluator, seed=2024, plane_dtype=torch.float32, keep_records=False,
+                           game_ids=range(first, first + games))
+        trace = []
+        for _ in range(9):
+            sp.play_ply()
+            trace.append((sp.search.action.clone(), sp.search.policy.clone()))
+        assert sp.env.illegal_count() == 0
+        runs[games] = trace
+        sp.close()
+    differs = False
+    for (a64, p64), (a32, p32) in zip(runs[64], runs[32]):
+        assert torch.equal(a64[32:], a32) and torch.equal(p64[32:], p32)
+        differs |= not torch.equal(a64[:32], a32)
+    assert differs                                          # other game ids do play other games
+
+
+def test_finished_slots_take_the_next_game_id_and_go_idle():
+    """A fixed set of game ids: finishing slots take the next id, then fall idle; every id is played exactly once and
+    drained with its id; staggered (unlogged) games yield no rows."""
+    from hive_alphazero_amd import mcts
+
+    def flat_eval(planes):
+        B = planes.shape[0]
+        return torch.full((B, 1584), 1.0 / 1584, device="cuda"), torch.zeros((B,), device="cuda")
+
+    sp = mcts.SelfPlay(16, 4, flat_eval, seed=3, plane_dtype=torch.float32, game_ids=range(1000, 1040))
+    seen = []
+    for _ in range(400):
+        sp.play_ply()
+        seen += [(e[2], len(e[1])) for e in sp.drain_finished()]
+        if sp.running() == 0:
+            break
+    assert sp.running() == 0 and sp.finished == 40
+    assert sorted(i for i, _ in seen) == list(range(1000, 1040))
+    assert all(n >= 7 for _, n in seen)                    # whole games from the opening (the queen must be down by turn 8)
+    assert sp.env.illegal_count() == 0 and sp.dropped_games == 0
+    sp.play_ply()
+    assert bool((sp.search.action == -2).all().item())     # idle slots are skipped by every kernel
+    sp.close()
+    sp2 = mcts.SelfPlay(16, 4, flat_eval, seed=3, plane_dtype=torch.float32, game_ids=range(16))
+    sp2.stagger(seed=1)
+    for _ in range(60):
+        sp2.play_ply()
+    assert sp2.finished == 16 and sp2.unrecorded_games + len(sp2.finished_games) == 16
+    assert sp2.unrecorded_games >= 12
+    sp2.close()
+
+
+def test_facade_under_the_reference_default_threading():
+    """woker/solo_play.py:153-165 searches with a ThreadPoolExecutor; a GamePlay call borrows its own single-board slot
+    (env_hive._EnginePool), so eight racing search threads over deep copies of one GamePlay stay consistent: every
+    simulation lands, the policy lives on the legal moves, nothing is refused by the env."""
+    import hive_alphazero_amd.solo_play as sp
+    from hive_alphazero_amd._lib import HiveError
+    from hive_alphazero_amd.env_hive import GamePlay, _EnginePool
+    rng = np.random.default_rng(8)
+    g = GamePlay(1050, 900)
+    for _ in range(13):
+        acts = g.actions()
+        g.move(int(acts[rng.integers(len(acts))]))
+    legal = g.actions()
+    old_threads, old_eps = sp.SEARCH_THREADS, sp.noise_eps
+    try:
+        sp.SEARCH_THREADS = 8
+        for trial in range(3):
+            player = sp.HivePlayer(pipes=[StubPipe() for _ in range(8)])
+            player.simulation_num_per_move = 96
+            np.random.seed(trial)
+            try:
+                move, (policy, visits) = player.action(g)
+            except HiveError as exc:                       # a torn load -> step -> store would surface here
+                raise AssertionError(f"env refused a move under threading: {exc}")
+            policy = np.asarray(policy)
+            assert move in legal and set(np.nonzero(policy)[0]) <= set(legal)
+            assert abs(policy.sum() - 1.0) < 1e-6
+            root = player.tree[g.state_key]
+            assert sum(e.n for e in root.a.values()) == visits >= 96 - 8      # racing first simulations may all see an empty tree
+            for entry in player._table.values():
+                if entry.moves is not None:
+                    assert (entry.n >= 0).all() and entry.sum_n == int(entry.n.sum())      # every virtual loss taken back
+        assert 1 <= _EnginePool.get(None).created <= 9
+    finally:
+        sp.SEARCH_THREADS, sp.noise_eps = old_threads, old_eps
+
+
+def test_facade_single_move_latency():
+    """Latency of the single-game façade (BASELINE configs[0]-shaped use): one GamePlay.move = load, step, legal set and
+    store in one borrowed slot.  Recorded under gpurun_out/ for DESIGN.md; the bound only catches a regression to
+    several round trips per call."""
+    from hive_alphazero_amd.env_hive import GamePlay
+    rng = np.random.default_rng(3)
+    g = GamePlay(1050, 900)
+    t_move, t_over, t_enc = [], [], []
+    for ply in range(40):
+        acts = g.actions()
+        if not acts or g.game_is_over():
+            break
+        a = int(acts[rng.integers(len(acts))])
+        t0 = time.perf_counter(); g.move(a); t1 = time.perf_counter()
+        g.game_is_over(); t2 = time.perf_counter()
+        g.encode_board(); t3 = time.perf_counter()
+        t_move.append(t1 - t0); t_over.append(t2 - t1); t_enc.append(t3 - t2)
+    med = {k: round(float(np.median(v[5:])) * 1e6, 1) for k, v in (("move_us", t_move), ("game_is_over_us", t_over), ("encode_board_us", t_enc))}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "facade_latency.json"), "w") as f:
+        json.dump(med, f)
+    print("facade latency (median us):", med)
+    assert med["move_us"] < 5000

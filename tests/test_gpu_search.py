@@ -146,9 +146,70 @@ def test_selfplay_engine_runs_and_stays_legal():
     sp.close()
 
 
+def test_uct_kernels_reproduce_reference_golden():
+    """SURVEY row a20 on the GPU: UCT_search (HIVE_SEARCH_UCT mode of csrc/hive_search.hip over the env kernels) against the
+    TRUE reference's UCTNode search (tests/golden/uct.json, written by oracle/gen_golden.py from alpha_zero/MCTS_chess.py):
+    root visit counts, total values (fp32, bit for bit) and the chosen move."""
+    import json
+    import os
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.MCTS_chess import UCT_search, get_policy
+    from hive_alphazero_amd.env_hive import GamePlay
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "uct.json")) as f:
+        gold = json.load(f)
+    for case in gold["cases"]:
+        g = GamePlay(1050, 900)
+        for a in case["prefix"]:
+            g.move(a)
+        best, root, extra = UCT_search(g, case["reads"], _host_stub_evaluator)
+        N, W = root.child_number_visits, root.child_total_value
+        assert N.dtype == np.float32 and W.dtype == np.float32 and extra is None
+        assert [[int(i), float(N[i]), float(W[i])] for i in np.nonzero(N)[0]] == case["visits"]
+        assert best == case["best"]
+        pol = get_policy(root)
+        assert pol.dtype == np.float32 and abs(float(pol.sum()) - 1.0) < 1e-6
+        assert N.sum() == case["reads"] - 1                 # the first read expands the root
+        assert set(np.nonzero(root.child_priors)[0]) <= set(g.actions()) and root.action_idxes == g.actions()
+
+
+def test_uct_kernels_match_sequential_restatement_in_batch():
+    """The same search for 24 positions in lock step at 150 reads (deeper trees than the golden file holds, stacked
+    beetles, finished games reached inside the tree) against tests/uct_ref.py -- the restatement pinned to the reference by
+    tests/test_host_cpu.py -- over the CPU oracle env: N and W of every root edge bit for bit."""
+    assert torch.cuda.is_available()
+    from oracle_env import OracleGamePlay
+    from uct_ref import uct_reads
+    from hive_alphazero_amd.MCTS_chess import uct_search_batch
+    from hive_alphazero_amd.env_hive import GamePlay
+    rng = np.random.default_rng(77)
+    envs, recs, hists = [], [], []
+    for k in range(24):
+        g, o = GamePlay(1050, 900), OracleGamePlay()
+        for _ in range(int(rng.integers(0, 46))):
+            acts = g.actions()
+            if not acts or g.game_is_over():
+                break
+            a = int(acts[rng.integers(len(acts))])
+            g.move(a); o.move(a)
+        envs.append(o); recs.append(g._rec.copy()); hists.append(g._hist.copy())
+    reads = 150
+    best, N, W, P = uct_search_batch(np.stack(recs), np.stack(hists), reads, _host_stub_evaluator)
+    N, W, P, best = N.cpu().numpy(), W.cpu().numpy(), P.cpu().numpy(), best.cpu().numpy()
+    deep = 0
+    for k, o in enumerate(envs):
+        rn, rw, rp, rbest = uct_reads(o, reads, stub_predict)
+        assert np.array_equal(N[k], rn), k
+        assert np.array_equal(W[k], rw), k
+        assert np.array_equal(P[k], rp), k
+        if rn.sum() > 0:
+            assert int(best[k]) == rbest
+        deep += int(rn.max() > 20)
+    assert deep >= 8                                        # trees several levels deep, not just root fans
+
+
 def test_uct_search_and_model_api_gpu(golden_games):
-    """The array-tree search (MCTS_chess.UCT_search) and the pipe-served evaluator (api_hive.HiveModelAPI)
-    on the GPU env / GPU net."""
+    """UCT_search with the real network (InferenceNet fp32 and the plain ChessNet, evaluated NCHW like MCTS_chess.py:133-141)
+    and the pipe-served evaluator (api_hive.HiveModelAPI) on the GPU env / GPU net."""
     assert torch.cuda.is_available()
     from hive_alphazero_amd.MCTS_chess import UCT_search, get_policy
     from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
@@ -237,9 +298,10 @@ def test_selfplay_records_match_env_planes(tmp_path):
         return p, v
 
     sp = mcts.SelfPlay(48, 6, cheap_eval, seed=3, plane_dtype=torch.float32)
-    sp.stagger(seed=4)
     checked = 0
-    for _ in range(14):
+    for _ in range(56):                      # from the opening: rows only exist for games logged from their first ply
+        if len(sp.finished_games) >= 3:
+            break
         boards, hist = sp.env.export_state()
         want = sp.env.encode(torch.float32, "hwc").cpu().numpy()
         over, _ = sp.env.terminal()
@@ -258,12 +320,16 @@ def test_selfplay_records_match_env_planes(tmp_path):
     assert checked > 300 and sp.env.illegal_count() == 0
     assert len(sp.finished_games) > 0
     rows = sp.finished_game_rows(0)
-    vw = sp.finished_games[0][0]
+    vw, plies, gid = sp.finished_games[0]
+    assert 0 <= gid < 48 + sp.finished and len(rows) == len(plies) >= 7
+    assert [r[3] for r in rows if r[3][1] == 1] == [[(len(rows) + 1) // 2, 1], [len(rows) // 2, 1]]     # [game_len, counter]
     assert all(len(r) == 4 and np.asarray(r[0]).shape == (12, 12, 56) and len(r[1]) == 1584 for r in rows)
     assert set(r[2] for r in rows) <= ({-1} if vw == 0 else {1, -1})
     path = records.flush_buffer(rows, str(tmp_path))
     back = records.load_data(path)
     assert len(back) == len(rows)
+    taken = sp.drain_finished()
+    assert len(taken) >= 1 and sp.finished_games == [] and sp.dropped_games == 0
     sp.close()
 
 
@@ -276,9 +342,10 @@ def test_selfplay_to_training_loop_closes():
     torch.manual_seed(0)
     net = ChessNet().cuda()
     sp = mcts.SelfPlay(64, 4, InferenceNet(net.eval()), seed=21)
-    sp.stagger(seed=22)
-    for _ in range(12):
+    for _ in range(56):
         sp.play_ply()
+        if len(sp.finished_games) >= 3:
+            break
     sp._retire_finished()
     assert sp.finished_games
     rows = [r for k in range(min(3, len(sp.finished_games))) for r in sp.finished_game_rows(k)]

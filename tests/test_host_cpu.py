@@ -1,6 +1,6 @@
-"""CPU-only checks: the C-ABI library loads and exports every declared symbol, host packing /
-record helpers, UCTNode and self_play_buffer mirrors against the reference's golden outputs
-(driven by the oracle env = BASELINE config C1), and the world-size-2 sharding path over gloo."""
+"""CPU-only checks: the C-ABI library loads and exports every declared symbol, host packing / record helpers, the
+test-side checkers (UCT restatement, caller drivers) and the sequential HivePlayer mirror against the reference's
+golden outputs (driven by the oracle env = BASELINE config C1), and the world-size-2 sharding path over gloo."""
 import gzip
 import json
 import os
@@ -112,43 +112,39 @@ def test_records_wire_format(tmp_path, golden_games):
     assert back[0][2] == pytest.approx(1 * 0.99 ** (2 - 1)) and back[2][2] == 1     # optimize.py:55-58
 
 
-def test_uctnode_matches_reference():
+def test_uct_restatement_matches_reference():
+    """tests/uct_ref.py (the checker the GPU tests hold the HIVE_SEARCH_UCT kernels against) reproduces the TRUE reference's
+    UCTNode search (tests/golden/uct.json, oracle/gen_golden.py uct): visits, total values and the chosen move."""
     from mcts_stub import stub_predict
     from oracle_env import OracleGamePlay
-    from hive_alphazero_amd.MCTS_chess import DummyNode, UCTNode
+    from uct_ref import uct_reads
     with open(os.path.join(GOLD, "uct.json")) as f:
         gold = json.load(f)
     for case in gold["cases"]:
         g = OracleGamePlay()
         for a in case["prefix"]:
             g.move(a)
-        root = UCTNode(g, move=None, parent=DummyNode())
-        for _ in range(case["reads"]):
-            leaf = root.select_leaf()
-            p, v = stub_predict(leaf.game.encode_board())
-            if leaf.game.game_is_over():
-                leaf.backup(v)
-                continue
-            leaf.expand(p)
-            leaf.backup(v)
-        nz = np.nonzero(root.child_number_visits)[0]
-        got = [[int(i), float(root.child_number_visits[i]), float(root.child_total_value[i])] for i in nz]
-        assert got == case["visits"]
-        assert int(np.argmax(root.child_number_visits)) == case["best"]
+        N, W, _, best = uct_reads(g, case["reads"], stub_predict)
+        assert [[int(i), float(N[i]), float(W[i])] for i in np.nonzero(N)[0]] == case["visits"]
+        assert best == case["best"]
 
 
-def test_self_play_buffer_matches_reference():
-    """BASELINE config C1: one self-play game through the drop-in caller on the CPU env path."""
+def test_selfplay_golden_through_the_sequential_search():
+    """BASELINE config C1: one whole self-play game (sequential HivePlayer mirror, stub evaluator, CPU env) against the
+    rows the TRUE reference's self_play_buffer wrote (tests/golden/selfplay.json.gz); the caller loop itself is the
+    test-side driver tests/caller_harness.py."""
     import hive_alphazero_amd.solo_play as sp
-    from hive_alphazero_amd.self_play import self_play_buffer
+    from caller_harness import selfplay_game
     from mcts_stub import StubPipe
     from oracle_env import OracleGamePlay
     with gzip.open(os.path.join(GOLD, "selfplay.json.gz"), "rt") as f:
         gold = json.load(f)
     sp.SEARCH_THREADS = 1
     np.random.seed(gold["seed"])
-    data, value_white = self_play_buffer([[StubPipe()]], make_env=OracleGamePlay, simulations=gold["sims"])
-    assert value_white == gold["value_white"]
+    pipes = [StubPipe()]
+    players = [sp.HivePlayer(pipes=pipes), sp.HivePlayer(pipes=pipes)]
+    data, value_white = selfplay_game(OracleGamePlay(), lambda side: players[side], sims=gold["sims"])
+    assert [value_white] == gold["value_white"]
     assert len(data) == len(gold["rows"])
     for (state, policy, value, lens), row in zip(data, gold["rows"]):
         arr = np.asarray(state, dtype=np.float32)
@@ -200,18 +196,61 @@ def test_sharding_world_size_2_gloo(tmp_path):
     assert res["total"] == res["want"] and res["units"] == res["n"] and res["slowest"] == 2.0
 
 
-def test_sl_get_buffer_matches_reference():
-    """woker/sl.py::get_buffer mirror on recorded games (a finished game with bot-weighted moves, a game with
-    an out-of-turn step that triggers skip_turn, an unfinished prefix) -- CPU env path."""
-    from hive_alphazero_amd.sl import decode_piece, get_buffer
+def test_recorded_game_golden_on_the_cpu_env():
+    """The reference's SL ingest rows (tests/golden/sl.json.gz: a finished game with bot-weighted moves, a game with an
+    out-of-turn step that triggers skip_turn, an unfinished prefix) replayed step by step over the CPU oracle env."""
+    from caller_harness import replay_recorded_game
     from oracle_env import OracleGamePlay
-    assert decode_piece("Q") == "<class 'pieces.Queen'>0" and decode_piece("G3") == "<class 'pieces.Grasshopper'>2"
     with gzip.open(os.path.join(GOLD, "sl.json.gz"), "rt") as f:
         gold = json.load(f)
     for case in gold["cases"]:
-        data, _ = get_buffer(case["steps"], make_env=OracleGamePlay)
+        data = replay_recorded_game(OracleGamePlay(), case["steps"])
         assert len(data) == len(case["rows"]) > 0
         for (state, policy, value, lens), row in zip(data, case["rows"]):
             assert int(zlib.crc32(np.asarray(state, dtype=np.float32).tobytes())) == row["crc"]
             assert [[i, float(x)] for i, x in enumerate(policy) if x != 0] == row["pol"]
             assert value == row["v"] and lens == row["lens"]
+
+
+def test_sl_schedule_host_logic():
+    """hive_alphazero_amd.sl: step decoding and the host-side replay plan (no GPU)."""
+    from hive_alphazero_amd import sl
+    assert sl.decode_piece("Q") == "<class 'pieces.Queen'>0" and sl.decode_piece("G3") == "<class 'pieces.Grasshopper'>2"
+    assert sl.step_action(["Q", "N", "13", "W", 0]) == 858           # Start_Tile ('N','13') = cell 78, slot 0
+    plan = sl._schedule([["Q", "N", "13", "W", 0], ["A1", "M", "13", "B", 1], ["A2", "M", "12", "B", 0]])
+    assert [p[0] for p in plan] == [False, False, True]              # black moving twice in a row needs a skip
+    assert [p[4] for p in plan] == [1, 1, 2] and plan[1][3] is True
+
+
+def test_selfplay_worker_shards_games_by_global_id(tmp_path):
+    """SURVEY 8e / woker/self_play.py:37-75,100-112: SelfPlayWorker spawns one child per GPU (HIP_VISIBLE_DEVICES set for the
+    child before it starts), hands rank r the contiguous shard of the global game ids, gathers the finished games, prints
+    the progress line every 10 games and flushes rows every N games.  With a GPU-free stand-in worker at world size 2:
+    every game id is played exactly once on the right device, and the merged result equals the world-size-1 result."""
+    import itertools
+    import fake_selfplay_worker as fw
+    from hive_alphazero_amd import dist as hd
+    from hive_alphazero_amd.self_play import SelfPlayWorker
+    # rank -> game ids: contiguous shards of a fixed total; strided when open-ended; unique across ranks either way
+    assert [list(hd.game_id_stream(r, 3, 10)) for r in range(3)] == [[0, 1, 2, 3], [4, 5, 6], [7, 8, 9]]
+    opened = [list(itertools.islice(hd.game_id_stream(r, 4), 3)) for r in range(4)]
+    assert opened == [[0, 4, 8], [1, 5, 9], [2, 6, 10], [3, 7, 11]]
+    runs = {}
+    for gpus in ([0], [0, 1]):
+        lines = []
+        w = SelfPlayWorker(total_games=23, games_per_gpu=4, sims=2, gpus=gpus, seed=7, datapath=str(tmp_path / f"w{len(gpus)}"),
+                           games_per_file=10, report_every=10, worker=fw.worker, log=lines.append)
+        res = w.start(timeout_s=120)
+        assert list(res) == list(range(23))
+        lo1 = hd.shard(23, 1, len(gpus))[0] if len(gpus) > 1 else 23
+        for g, (vw, rows) in res.items():
+            assert rows[0][0][2] == ("0" if g < lo1 else "1")          # the child saw exactly its own GPU
+            rows[0][0].pop()
+            assert (vw, rows) == fw.fabricate(7, g)
+        assert len(lines) == 2 and lines[0].startswith(" Total_game 10 ---") and "White_Win %" in lines[1]
+        assert len(w.files) == 3 and w.leaf_kinds == {"root_evaluated": 23}   # 10 + 10 + the final partial flush
+        data = [r for f in w.files for r in json.load(open(f))]
+        assert len(data) == sum(len(rows) for _, rows in res.values())
+        runs[len(gpus)] = res
+    assert runs[1] == runs[2]
+    assert "HIP_VISIBLE_DEVICES" not in os.environ or os.environ["HIP_VISIBLE_DEVICES"] != "1"

@@ -102,21 +102,30 @@ def test_gameplay_facade_matches_golden_game(golden_games):
 
 
 @pytest.mark.gpu
-def test_sl_get_buffer_gpu_env():
-    """The SL ingest (woker/sl.py::get_buffer mirror) over the HIP-backed GamePlay: skip_turn, encode_action,
-    encode_board(player) and move(with_skip=False) against the reference's rows."""
+def test_sl_ingest_gpu_matches_reference_rows():
+    """the batched SL ingest (hive_alphazero_amd.sl.get_buffers: every recorded game advances in the same
+    kernel launches) against the rows the TRUE reference's woker/sl.py::get_buffer wrote for the same recorded games
+    (tests/golden/sl.json.gz): planes, one-hot / bot-weighted policy, value, [game_len, counter] -- plus a game with an
+    illegal step, which must yield no rows without disturbing the others."""
     import zlib
     import torch
     assert torch.cuda.is_available()
-    from hive_alphazero_amd.sl import get_buffer
+    from hive_alphazero_amd.sl import get_buffer, get_buffers
     with gzip.open(os.path.join(os.path.dirname(GOLD), "sl.json.gz"), "rt") as f:
         gold = json.load(f)
-    for case in gold["cases"][:2]:
-        data, _ = get_buffer(case["steps"])
-        assert len(data) == len(case["rows"])
+    games = [c["steps"] for c in gold["cases"]]
+    broken = [list(s) for s in games[0][:9]]
+    broken[6] = ["Q", "H", "7", broken[6][3], 0]           # a queen drop far from the hive: not legal
+    out = get_buffers(games + [broken])
+    assert out[-1] == []
+    for data, case in zip(out, gold["cases"]):
+        assert len(data) == len(case["rows"]) > 0
         for (state, policy, value, lens), row in zip(data, case["rows"]):
             assert int(zlib.crc32(np.asarray(state, dtype=np.float32).tobytes())) == row["crc"]
+            assert [[i, float(x)] for i, x in enumerate(policy) if x != 0] == row["pol"]
             assert value == row["v"] and lens == row["lens"]
+    one, same = get_buffer(games[1])
+    assert same is games[1] and len(one) == len(gold["cases"][1]["rows"])
 
 
 DEEP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mcts_deep.json.gz")
