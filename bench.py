@@ -24,6 +24,7 @@ HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md "HB
 # HBM bytes per board from the PMC passes in profiles/r01_movegen_pmc_traffic.md: (2 x FETCH_SIZE + WRITE_SIZE) KiB
 # per 4096-board launch = 1,614,848 B (gfx950 FETCH_SIZE correction applied); not measurable from inside bench.py
 MOVEGEN_TRAFFIC_BYTES_PER_BOARD = 394
+MOVEGEN_TRAFFIC_SOURCE = "profiles/r01_movegen_pmc_traffic.md (separate rocprofv3 --pmc passes of this command; not measured in-run)"
 # the bound that actually binds: 489 VALU wave-instructions per board (PMC, profiles/r01_movegen_pmc_valu.md), each
 # occupying one of the 1024 SIMDs for 4 cycles at 2.4 GHz
 MOVEGEN_VALU_PER_BOARD = 489
@@ -84,43 +85,100 @@ GFLOP_PER_LEAF = 6.560114816         # 3,280,057,408 MAC x 2 per board, SURVEY.m
 MFMA_PEAK_TFLOPS = 2500.0            # MI355X dense bf16/fp16 matrix peak, MI355X_MICROARCH.md
 
 
-def selfplay_measure(args, local_rank, world):
-    """BASELINE configs[2]: `games` concurrent self-play games, `sims` simulations per move, random-init
-    ChessNet in bf16.  Games are staggered over plies 0..53 so the timed plies see the steady state."""
+def _leaf_accounting(hist, executed, el):
+    """MFMA roofline of a self-play window.  `executed` = boards the network evaluated (every simulation evaluates one
+    board per game slot, whatever the leaf turned out to be); `needed` = simulations whose leaf really was a position
+    to evaluate (root / new position), from the search's leaf histogram."""
+    needed = hist.get("root_evaluated", 0) + hist.get("expanded_evaluated", 0)
+    tf = executed * GFLOP_PER_LEAF / el / 1e3
+    return {"leaf_kinds": hist, "leaf_evals_executed": executed, "leaf_evals_needed": needed,
+            "useful_leaf_fraction": round(needed / max(executed, 1), 4),
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / MFMA_PEAK_TFLOPS, 5), "traffic": None,
+                         "achieved_needed_only": round(needed * GFLOP_PER_LEAF / el / 1e3, 2),
+                         "frac_needed_only": round(needed * GFLOP_PER_LEAF / el / 1e3 / MFMA_PEAK_TFLOPS, 5),
+                         "note": "achieved counts the FLOPs executed (fixed batch of games x slots boards per simulation); "
+                                 "*_needed_only counts only leaves that had to be evaluated"}}
+
+
+def selfplay_measure(args, rank, local_rank, world):
+    """BASELINE M1 (games/min at `sims` simulations per move, random-init ChessNet in bf16, root noise on), two ways:
+
+    whole_games   BASELINE configs[2] literally: `games` games from the opening position, every one played to its end
+                  (queen surrounded or the 55-turn cap), no replacement; value = games / wall time.  Slots whose game
+                  has ended idle until the last game ends, so this is the conservative figure.
+    steady_state  the same engine with finished games replaced at once and the games staggered over plies 0..53, i.e.
+                  what a long self-play run sustains; finished games COUNTED over the timed window (and the old
+                  plies / mean-length extrapolation beside it)."""
     import torch
+    from hive_alphazero_amd import dist as hd
     from hive_alphazero_amd import mcts
     from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
     torch.manual_seed(0)
     net = InferenceNet(ChessNet().cuda().eval(), dtype=torch.bfloat16)
-    sp = mcts.SelfPlay(args.games, args.sims, net, device=local_rank, slots=args.slots, seed=1234 + local_rank)
-    sp.stagger(seed=77 + local_rank)
-    for _ in range(args.selfplay_warmup):
-        sp.play_ply()
-    torch.cuda.synchronize()
-    f0 = sp.finished
-    t0 = time.perf_counter()
-    for _ in range(args.selfplay_plies):
-        sp.play_ply()
-    sp._retire_finished()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    illegal = sp.env.illegal_count()
-    finished = sp.finished - f0
-    mean_len = (sum(sp.finished_lengths) / len(sp.finished_lengths) - 1.0) if sp.finished_lengths else 54.0
-    leafs = args.games * args.sims * args.selfplay_plies
-    out = {
-        "workload": f"selfplay_{args.games}x{args.sims}sims" + (f"_slots{args.slots}" if args.slots > 1 else ""),
-        "games_per_min": round(args.games * args.selfplay_plies / mean_len / el * 60.0, 2),
-        "finished_games_in_window": finished, "window_plies": args.selfplay_plies, "window_s": round(el, 3),
-        "mean_plies_per_finished_game": round(mean_len, 2), "ms_per_ply": round(el / args.selfplay_plies * 1e3, 2),
-        "leaf_evals_per_s": round(leafs / el, 1),
-        "roofline": {"bound": "mfma", "achieved": round(leafs * GFLOP_PER_LEAF / el / 1e3, 2), "peak": MFMA_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(leafs * GFLOP_PER_LEAF / el / 1e3 / MFMA_PEAK_TFLOPS, 5), "traffic": None},
-        "net": "ChessNet 20-block ResNet, random init (torch.manual_seed(0)), bf16 channels-last, HIP-graph replay",
-        "illegal_moves": illegal,
-        "results": {"white": sp.white_wins, "black": sp.black_wins, "draw_or_cap": sp.draws},
-    }
-    sp.close()
+    out = {"workload": f"selfplay_{args.games}x{args.sims}sims" + (f"_slots{args.slots}" if args.slots > 1 else ""),
+           "net": "ChessNet 20-block ResNet, random init (torch.manual_seed(0)), bf16 channels-last, HIP-graph replay"}
+
+    if args.whole_games:
+        lo = rank * args.games                              # global game ids: rank r plays games r*G .. (r+1)*G - 1
+        sp = mcts.SelfPlay(args.games, args.sims, net, device=local_rank, slots=args.slots, seed=1234, keep_records=False,
+                           game_ids=range(lo, lo + args.games))
+        sp.play_ply()                                       # graph capture / GEMM tuning outside the timed region
+        torch.cuda.synchronize()
+        sp.close()
+        sp = mcts.SelfPlay(args.games, args.sims, net, device=local_rank, slots=args.slots, seed=1234, keep_records=False,
+                           game_ids=range(lo, lo + args.games))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        plies = 0
+        while True:
+            sp.play_ply()
+            plies += 1
+            if sp.running() == 0 or plies > 60:
+                break
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        executed = plies * args.games * args.sims           # every simulation evaluates one board per game slot
+        whole = {"games": sp.finished, "wall_s": round(el, 3), "plies_played": plies,
+                 "games_per_min": round(sp.finished / el * 60.0, 2),
+                 "mean_plies_per_game": round(sp.mean_game_length(), 2), "ms_per_ply": round(el / plies * 1e3, 2),
+                 "illegal_moves": sp.env.illegal_count(),
+                 "results": {"white": sp.white_wins, "black": sp.black_wins, "draw_or_cap": sp.draws}}
+        whole.update(_leaf_accounting(sp.leaf_histogram(), executed, el))
+        sp.close()
+        out["whole_games"] = whole
+        out["games_per_min"] = whole["games_per_min"]
+
+    if args.selfplay_plies > 0:
+        sp = mcts.SelfPlay(args.games, args.sims, net, device=local_rank, slots=args.slots, seed=1234, keep_records=False,
+                           game_ids=hd.game_id_stream(rank, world))
+        sp.stagger(seed=77 + rank)
+        for _ in range(args.selfplay_warmup):
+            sp.play_ply()
+        torch.cuda.synchronize()
+        f0, h0 = sp.finished, sp.leaf_histogram()
+        t0 = time.perf_counter()
+        for _ in range(args.selfplay_plies):
+            sp.play_ply()
+        sp._retire_finished()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        finished = sp.finished - f0
+        h1 = sp.leaf_histogram()
+        hist = {k: h1[k] - h0[k] for k in h1}
+        executed = args.selfplay_plies * args.games * args.sims
+        mean_len = (sum(sp.finished_lengths) / len(sp.finished_lengths) - 1.0) if sp.finished_lengths else 54.0
+        steady = {"window_plies": args.selfplay_plies, "window_s": round(el, 3), "finished_games_in_window": finished,
+                  "games_per_min_counted": round(finished / el * 60.0, 2),
+                  "games_per_min_extrapolated": round(args.games * args.selfplay_plies / mean_len / el * 60.0, 2),
+                  "mean_plies_per_finished_game": round(mean_len, 2), "ms_per_ply": round(el / args.selfplay_plies * 1e3, 2),
+                  "illegal_moves": sp.env.illegal_count(),
+                  "results": {"white": sp.white_wins, "black": sp.black_wins, "draw_or_cap": sp.draws}}
+        steady.update(_leaf_accounting(hist, executed, el))
+        sp.close()
+        out["steady_state"] = steady
+        out.setdefault("games_per_min", steady["games_per_min_counted"])
+        out["leaf_evals_per_s"] = round(executed / el, 1)
     if args.cpu_baseline_selfplay and world == 1:            # host baselines are an N = 1 measurement
         out["cpu_baseline"] = selfplay_cpu_baseline(args.sims)
     return out
@@ -191,7 +249,9 @@ def main():
     ap.add_argument("--games", type=int, default=1024, help="concurrent self-play games per GPU (BASELINE configs[2])")
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--slots", type=int, default=1, help="leaves in flight per tree (virtual loss); BASELINE configs[4] uses 250 sims")
-    ap.add_argument("--selfplay-plies", type=int, default=6, help="timed plies of the self-play side measurement (0 = skip)")
+    ap.add_argument("--selfplay-plies", type=int, default=40, help="timed plies of the steady-state self-play window (0 = skip)")
+    ap.add_argument("--no-whole-games", dest="whole_games", action="store_false",
+                    help="skip the whole-game self-play leg (games from the opening to their end)")
     ap.add_argument("--selfplay-warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline-selfplay", dest="cpu_baseline_selfplay", action="store_false")
     ap.add_argument("--train-steps", type=int, default=10, help="timed steps of the training-step side measurement (0 = skip)")
@@ -255,13 +315,33 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)
-    tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    # the timed region is the K launches between the two barrier + synchronize brackets, measured with HIP events on the
+    # launch stream (a host clock around a 0.2 ms region mostly measures the closing synchronize); max over ranks
+    tt = torch.tensor([dev_ms * 1e-3, wall], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    wall_max = float(tt.item())
+    wall_max, host_wall_max = float(tt[0].item()), float(tt[1].item())
     mean_legal = float(count.float().mean().item())
 
     t_side0 = time.perf_counter()
+    # side measurement: legal set AND its compaction into sorted action ids (hive_list_kernel = GamePlay.encode_action,
+    # env_hive.py:287-304) -- what GamePlay.actions() returns
+    with_list = None
+    if rank == 0:
+        lst = torch.empty((n, 256), dtype=torch.int16, device="cuda")
+        lp = ctypes.c_void_p(lst.data_ptr())
+        for _ in range(10):
+            L.hive_movegen_launch(bp, n, mp, cp, lp, sp)
+        torch.cuda.synchronize()
+        l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        l0.record(stream)
+        for _ in range(args.steps):
+            L.hive_movegen_launch(bp, n, mp, cp, lp, sp)
+        l1.record(stream)
+        torch.cuda.synchronize()
+        lms = l0.elapsed_time(l1) / args.steps
+        with_list = {"Mboards_per_s": round(n / lms / 1e3, 2), "ms_per_step": round(lms, 6),
+                     "note": "hive_piece_kernel + hive_list_kernel (mask -> ascending int16 ids), 2 launches per step"}
     # side measurement: the same 4096-board steps, independent batches issued round-robin on 4 HIP streams
     # (what a self-play engine with several game groups does); NOT the headline value
     overlapped = None
@@ -340,13 +420,13 @@ def main():
         assert torch.equal(hm, mask.cpu())
 
     selfplay = None
-    if args.selfplay_plies > 0:
+    if args.selfplay_plies > 0 or args.whole_games:
         try:
-            selfplay = selfplay_measure(args, local_rank, world)
+            selfplay = selfplay_measure(args, rank, local_rank, world)
         except Exception as exc:                 # the headline line must still come out
             selfplay = {"error": repr(exc), "games_per_min": 0.0, "leaf_evals_per_s": 0.0}
         if world > 1:
-            t = torch.tensor([selfplay["games_per_min"], selfplay["leaf_evals_per_s"]], dtype=torch.float64, device="cuda")
+            t = torch.tensor([selfplay.get("games_per_min", 0.0), selfplay.get("leaf_evals_per_s", 0.0)], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             selfplay["games_per_min_all_gpus"] = round(float(t[0].item()), 2)
             selfplay["leaf_evals_per_s_all_gpus"] = round(float(t[1].item()), 1)
@@ -370,6 +450,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(wall_max * 1e3 / args.steps, 6),
+            "timing": "HIP events on the launch stream inside the barrier+synchronize brackets, max over ranks",
+            "host_wall_ms_per_step": round(host_wall_max * 1e3 / args.steps, 6),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -379,10 +461,12 @@ def main():
                        "corpus": "GPU random playouts, every ply sampled, seed 1000+rank", "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": MOVEGEN_TRAFFIC_BYTES_PER_BOARD * n,
+                         "traffic_source": MOVEGEN_TRAFFIC_SOURCE,
                          "kernel": "hive_piece_kernel<false>", "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_BOARD,
                          "note": "VALU-issue bound (489 wave-instructions per board), not HBM bound: see saturated.valu_issue_roof; "
                                  "4096 boards = 256 workgroups x 11 waves = one workgroup per CU"},
+            "movegen_with_sorted_id_list": with_list,
             "overlapped_4_streams": overlapped,
             "saturated": sat,
             "host_buffers_pcie_inclusive": pcie,

@@ -423,8 +423,12 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
 #ifndef HIVE_WAVE_SLOTS
 #define HIVE_WAVE_SLOTS 0x6573498A210ull      /* hex digit w (lowest = wave 0) = piece slot of wave w */
 #endif
+#ifndef HIVE_PIN_IDS
+#define HIVE_PIN_IDS 0xFFFFFFFF210ull         /* hex digit w = share (0..2) of the one-hive test wave w takes first, F = none */
+#endif
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wv = (int)((HIVE_WAVE_SLOTS >> (4 * wave_id)) & 15ull);      // the piece slot this wave works on
+    const int pin_id = (int)((HIVE_PIN_IDS >> (4 * wave_id)) & 15ull);
     const int nthreads = NW * 64;
     const long long gbase = (long long)blockIdx.x * G;
 #ifdef HIVE_DBG_ITERS
@@ -489,15 +493,15 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     const unsigned turn = state_byte(st, 33);
     const int stm = (turn & 1u) ? 0 : 1;
     const int type = slot_type(wv);
-    if (wave_id == kPinWaves - 1) {      // published together with this wave's pin results (pin_done)
+    if (pin_id == kPinWaves - 1) {       // published together with this wave's pin results (pin_done)
         BB nmt;
         const BB pl = placement_board(sm.state[bl], sm.occ[bl], sm.topw[bl], nmt);
         bb_store(sm.place[bl], pl);
         bb_store(sm.place[bl] + 6, nmt);
     }
-    if (wave_id < kPinWaves) {
+    if (pin_id < kPinWaves) {
         // the three lightest waves (Queen, Beetles) settle the one-hive question for the whole workgroup first
-        pin_phase<FULL>(sm, wave_id, lane);
+        pin_phase<FULL>(sm, pin_id, lane);
         HIVE_STAMP(4);
     }
     int q;

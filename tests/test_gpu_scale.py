@@ -92,8 +92,13 @@ def test_config4_1024_games_250_sims_four_slots_one_ply(bf16_net):
     assert bool((action[live & (count == 0)] == -1).all().item()) and bool((action[~live] == -2).all().item())
     hist = ts.leaf_histogram()
     # every in-flight slot of a live game is one histogram entry; a collision gives its visit back, nothing else is lost
-    assert bool((hist.sum(1)[live] == sims).all().item()) and bool((hist.sum(1)[~live] == 0).all().item())
-    assert bool((sum_n[live] == sims - 1 - hist[live][:, 4]).all().item())
+    # (a root that is a finished game is "searched" too: one new-finished-position leaf, then known-finished leaves)
+    assert bool((hist.sum(1) == sims).all().item()) and bool((hist[~live][:, [1, 2, 4]] == 0).all().item())
+    # (a line that returns to the root position through a transposition passes the root's edges twice: solo_play.py:188)
+    hits = ts.transposition_hits()
+    plain = live & (hits == 0)
+    assert bool((sum_n[plain] == sims - 1 - hist[plain][:, 4]).all().item()) and int(plain.sum().item()) > 100
+    assert bool((sum_n[live] >= sims - 1 - hist[live][:, 4]).all().item())
     assert bool((sum_n[live] > sims // 2).all().item())
     nodes = ts.node_counts()
     assert int(nodes.max().item()) <= sims and sims + slots < ts.max_nodes + 1
