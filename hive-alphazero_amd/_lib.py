@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "hive_search_set_game_ids", "hive_search_root_stats", "hive_search_leaf_histogram", "hive_search_sample_noise",
     # include/hive_nn.h
     "hive_nn_conv3x3", "hive_nn_resblock", "hive_nn_bn_workspace_floats", "hive_nn_bn_act_fwd", "hive_nn_bn_act_bwd",
-    "hive_nn_pack_conv3x3_weights",
+    "hive_nn_pack_conv3x3_weights", "hive_nn_conv3x3_wgrad", "hive_nn_wgrad_workspace_floats",
 ]
 
 
@@ -115,6 +115,8 @@ def load():
     L.hive_nn_bn_act_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i64, i32, i32, vp]
     L.hive_nn_bn_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
     L.hive_nn_pack_conv3x3_weights.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.hive_nn_conv3x3_wgrad.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.hive_nn_wgrad_workspace_floats.restype = i32
     for name in ABI_SYMBOLS:
         getattr(L, name)
     _lib = L

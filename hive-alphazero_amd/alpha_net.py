@@ -206,9 +206,11 @@ def _const(kind, cin, dev):
 
 
 class _Conv3x3(torch.autograd.Function):
-    """3x3 convolution of the training step on the hand-written MFMA kernel: forward and data gradient are
+    """3x3 convolution of the training step on the hand-written MFMA kernels: forward and data gradient are
     hive_nn_conv3x3 (the data gradient = the same kernel on dy with transposed, 180-degree-rotated weights, packed by
-    hive_nn_pack_conv3x3_weights); the weight gradient stays on the library (MIOpen) path."""
+    hive_nn_pack_conv3x3_weights); the weight gradient of the 256 -> 256 convolutions is hive_nn_conv3x3_wgrad (pixels as
+    the contraction dimension, transposing LDS reads); only the 56-channel stem's stays on the library (MIOpen) path."""
+    hip_wgrad = True
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -249,10 +251,23 @@ class _Conv3x3(torch.autograd.Function):
             _lib.check(L.hive_nn_pack_conv3x3_weights(p(wsrc), cin, 1, wcl, p(wt), st))
             dx = torch.empty_like(x)
             _lib.check(L.hive_nn_conv3x3(p(dy), 256, p(wt), p(_const("zero_bias", 0, dev)), None, p(dx), B, 0, st))
-        dw = torch.ops.aten.convolution_backward(dy, x, _const("weight_like", cin, dev), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                 (False, True, False))[1]
+        if cin == 256 and _Conv3x3.hip_wgrad:
+            taps = torch.empty((3, 3, 256, 256), dtype=torch.float32, device=dev)
+            _lib.check(L.hive_nn_conv3x3_wgrad(p(x), p(dy), p(taps), B, p(_wgrad_workspace(L, dev)), st))
+            dw = taps.permute(2, 3, 0, 1)                      # [k][c][ty][tx], the strides torch.channels_last gives a weight
+        else:
+            dw = torch.ops.aten.convolution_backward(dy, x, _const("weight_like", cin, dev), None, (1, 1), (1, 1), (1, 1), False,
+                                                     (0, 0), 1, (False, True, False))[1].float()
         db = dy.float().sum(dim=(0, 2, 3)) if ctx.has_bias else None
-        return dx, dw.float(), db
+        return dx, dw, db
+
+
+def _wgrad_workspace(L, dev):
+    """Per-device partial-sum scratch of hive_nn_conv3x3_wgrad (include/hive_nn.h)."""
+    key = ("wgrad_ws", dev.index)
+    if key not in _CONST_CACHE:
+        _CONST_CACHE[key] = torch.empty((L.hive_nn_wgrad_workspace_floats(),), dtype=torch.float32, device=dev)
+    return _CONST_CACHE[key]
 
 
 def _weight_layout(w):

@@ -323,8 +323,10 @@ class SelfPlay:
         """The k-th waiting finished game as the reference's rows."""
         return self.game_rows(self.finished_games[k])
 
-    def play_ply(self):
-        """One move for every game.  Returns the number of games that finished before this move."""
+    def play_ply(self, forced=None):
+        """One move for every game.  Returns the number of games that finished before this move.
+        forced: optional int32[games]; entries >= -1 replace the searched move of that slot (replaying a recorded game
+        through the record path; -2 = keep the search's choice)."""
         nd = self._retire_finished()
         boards, hist = self.env.export_state()
         action, policy, sum_n = self.search.search(boards, hist, active=self.active, selfplay=True,
@@ -347,6 +349,9 @@ class SelfPlay:
             oldest = min(self._start_ply)
             while self._log and self._log[0]["ply"] < oldest:
                 self._log.pop(0)
+        if forced is not None:
+            forced = torch.as_tensor(forced, dtype=torch.int32, device=self.device)
+            action = torch.where((forced >= -1) & (action != -2), forced, action)
         # the env re-derives the legal masks and refuses anything not in them: the search's edges come
         # from the same kernels, so illegal_count() must stay 0 (asserted by the tests)
         self.env.step(action, sync=False)

@@ -55,6 +55,16 @@ int hive_nn_bn_act_bwd(const void *dy, const void *x, const void *y, const float
  * of the data-gradient convolution: hive_nn_conv3x3(dy, 256, packed_T, ...) then returns dx of y = conv3x3(x, w). */
 int hive_nn_pack_conv3x3_weights(const float *w, int cin, int transpose, int channels_last, void *out, void *stream);
 
+/* Weight gradient of a 3x3 / stride 1 / zero-padded convolution with 256 input and 256 output channels (what autograd
+ * computes for ResBlock.conv1/conv2.weight in the training step, alpha_net.py:36-54,117-162):
+ *   dw[tap][k][c] = sum_{b, pixel} dy[b][pixel][k] * x[b][pixel + tap][c],   tap = (dy + 1) * 3 + (dx + 1)
+ *   x, dy  bf16 [batch][144][256] channels-last;  dw  f32 [9][256][256], overwritten (torch's weight.grad layout is
+ *   dw.view(3, 3, 256, 256).permute(2, 3, 0, 1)).  fp32 accumulation on the MFMA units over up to 32 board ranges, whose
+ *   partial sums a second kernel adds in a fixed order: the result is deterministic.
+ *   workspace: device f32[hive_nn_wgrad_workspace_floats()] (75 MB of partial sums), contents undefined between calls. */
+int hive_nn_wgrad_workspace_floats(void);
+int hive_nn_conv3x3_wgrad(const void *x, const void *dy, float *dw, int batch, float *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

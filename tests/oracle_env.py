@@ -62,6 +62,14 @@ class OracleGamePlay:
     def skip_turn(self):                 # env_hive.py:493-496 (state_key is not updated there)
         self._g.skip_turn()
 
+    def __deepcopy__(self, memo):        # solo_play.py:158 / MCTS_chess.py:104 copy the env once per simulation / child
+        c = OracleGamePlay.__new__(OracleGamePlay)
+        c._g = self._g.copy()
+        c.state = _State(c._g)
+        c.state.winner = self.state.winner
+        c.state_key = self.state_key
+        return c
+
     class _Tile:
         def __init__(self, x, y):
             self.index_xy = [x, y]
@@ -80,15 +88,3 @@ class OracleGamePlay:
 for _x in range(12):
     for _y in range(12):
         OracleGamePlay.board_matrix[_x, _y] = OracleGamePlay._Tile(_x, _y)
-
-
-class _Unused:
-    pass
-
-    def __deepcopy__(self, memo):
-        c = OracleGamePlay.__new__(OracleGamePlay)
-        c._g = self._g.copy()
-        c.state = _State(c._g)
-        c.state.winner = self.state.winner
-        c.state_key = self.state_key
-        return c

@@ -362,3 +362,62 @@ def test_selfplay_to_training_loop_closes():
     val = torch.tensor([float(v) for v in dataset[:8, 2]])
     assert np.isfinite(tr.step(x, pol, val))
     sp.close()
+
+
+def test_selfplay_rows_equal_reference_written_rows():
+    """SURVEY 8f-1 on the GPU path: the wire rows mcts.SelfPlay emits for a game -- planes, value, [game_len, counter] --
+    against the rows the TRUE reference's self_play_buffer wrote for that same game (tests/golden/selfplay.json.gz).
+    The golden file holds rows, not moves, so the moves are first recovered on the CPU oracle env (the action after which
+    the next recorded planes appear); slot 0 of a 4-game engine is then forced along them while the other slots play
+    freely.  (The visit policies differ by construction: the reference searched with numpy's noise stream.)"""
+    import copy
+    import gzip
+    import json
+    import os
+    import zlib
+    assert torch.cuda.is_available()
+    from oracle_env import OracleGamePlay
+    from hive_alphazero_amd import mcts
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "selfplay.json.gz"), "rt") as f:
+        gold = json.load(f)
+    rows = gold["rows"]
+    crc = lambda env: int(zlib.crc32(np.asarray(env.encode_board(), dtype=np.float32).tobytes()))
+    env, moves = OracleGamePlay(), []
+    assert crc(env) == rows[0]["crc"]
+    for k in range(len(rows)):
+        found = None
+        for a in env.actions():
+            nxt = copy.deepcopy(env)
+            nxt.move(a)
+            if k + 1 < len(rows):
+                if crc(nxt) == rows[k + 1]["crc"]:
+                    found = a
+                    break
+            elif nxt.game_is_over() and (nxt.state.winner == (250, 250, 250)) == (gold["value_white"][0] == 1):
+                found = a
+                break
+        assert found is not None, k
+        moves.append(found)
+        env.move(found)
+
+    def flat_eval(planes):
+        B = planes.shape[0]
+        return torch.full((B, 1584), 1.0 / 1584, device="cuda"), torch.zeros((B,), device="cuda")
+
+    sp = mcts.SelfPlay(4, 5, flat_eval, seed=9, plane_dtype=torch.float32, game_ids=range(4))
+    entry = None
+    for k in range(len(moves) + 1):
+        forced = torch.tensor([moves[k] if k < len(moves) else -2, -2, -2, -2], dtype=torch.int32)
+        sp.play_ply(forced)
+        done = [e for e in sp.drain_finished() if e[2] == 0]
+        if done:
+            entry = done[0]
+            break
+    assert entry is not None and sp.env.illegal_count() == 0
+    got = mcts.SelfPlay.game_rows(entry)
+    assert entry[0] == gold["value_white"][0] and len(got) == len(rows)
+    for (state, policy, value, lens), row in zip(got, rows):
+        assert int(zlib.crc32(np.asarray(state, dtype=np.float32).tobytes())) == row["crc"]
+        assert value == row["v"] and lens == row["lens"]
+        assert abs(sum(policy) - 1.0) < 1e-4
+    sp.close()

@@ -397,6 +397,40 @@ def test_hip_training_conv_matches_torch(cin, weights_cl):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 8, 37, 512])
+def test_hip_weight_gradient_matches_fp32_convolution_backward(batch):
+    """hive_nn_conv3x3_wgrad (pixels as the MFMA contraction, both operands through transposing LDS reads, split over
+    board ranges whose partial sums a second kernel adds) against aten.convolution_backward in fp32 on the same bf16 operands: every one of the
+    9 x 256 x 256 entries.  Products of bf16 values are exact in fp32, so only the summation order differs:
+    tolerance 2e-5 of the largest entry (sums of up to batch * 144 terms).  Batches 1 / 37 exercise single-board
+    and ragged board ranges; the border taps (zero halo) carry full weight because every pixel is non-zero."""
+    assert torch.cuda.is_available()
+    import ctypes
+    import hive_alphazero_amd as h
+    L = h.load()
+    g = torch.Generator(device="cuda").manual_seed(100 + batch)
+    x = torch.randn((batch, 256, 12, 12), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn((batch, 256, 12, 12), device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    taps = torch.full((3, 3, 256, 256), float("nan"), dtype=torch.float32, device="cuda")      # must be overwritten
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    ws = torch.full((L.hive_nn_wgrad_workspace_floats(),), float("nan"), dtype=torch.float32, device="cuda")    # scratch: any contents
+    rc = L.hive_nn_conv3x3_wgrad(p(x), p(dy), p(taps), batch, p(ws), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, L.hive_last_error()
+    torch.cuda.synchronize()
+    got = taps.permute(2, 3, 0, 1)
+    want = torch.ops.aten.convolution_backward(dy.float(), x.float(), torch.zeros((256, 256, 3, 3), device="cuda"), None, (1, 1), (1, 1),
+                                               (1, 1), False, (0, 0), 1, (False, True, False))[1]
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max().item()
+    assert err <= 2e-5 * want.abs().max().item() + 1e-6, (err, want.abs().max().item())
+    # a second call overwrites dw, it does not accumulate, and the fixed summation order makes it bit-identical
+    first = taps.clone()
+    L.hive_nn_conv3x3_wgrad(p(x), p(dy), p(taps), batch, p(ws), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(taps, first)
+
+
+@pytest.mark.gpu
 def test_inference_net_refresh_keeps_graphs_and_takes_new_weights():
     """After a training iteration the evaluator takes the new weights in place (the reference's workers re-read the
     checkpoint, self_play.py:37-75): the captured graph of a batch size keeps replaying, now with the new network."""

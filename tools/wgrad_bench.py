@@ -1,0 +1,59 @@
+"""hive_nn_conv3x3_wgrad vs MIOpen's weight-gradient convolution at the training batch, plus timing-only ablations
+(builds with -DHIVE_WG_ABL_*: results of those are wrong by construction)."""
+import ctypes, glob, os, subprocess, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SRC = os.path.join(ROOT, "hive-alphazero_amd", "csrc")
+OUT = os.path.join(ROOT, "build", "wg")
+VARIANTS = {"base": ["-DHIVE_WG_DEBUG"], "noatomic": ["-DHIVE_WG_ABL_NOATOMIC"], "nostage": ["-DHIVE_WG_ABL_NOSTAGE"],
+            "nostage_noatomic": ["-DHIVE_WG_ABL_NOSTAGE", "-DHIVE_WG_ABL_NOATOMIC"]}
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    for name, flags in VARIANTS.items():
+        so = os.path.join(OUT, f"wg_{name}.so")
+        srcs = [os.path.join(SRC, "hive_wgrad.hip"), os.path.join(SRC, "hive_env.hip")]
+        if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs):
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared"] + flags +
+                                  ["-o", so] + srcs)
+
+
+def timeit(fn, n=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+if __name__ == "__main__":
+    build()
+    if not torch.cuda.is_available():
+        sys.exit(0)
+    for B in [int(a) for a in sys.argv[1:]] or [512, 1024, 128]:
+        x = torch.randn((B, 256, 12, 12), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn((B, 256, 12, 12), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wl = torch.zeros((256, 256, 3, 3), dtype=torch.bfloat16, device="cuda").contiguous(memory_format=torch.channels_last)
+        lib = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, wl, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False)))
+        flop = 2 * 256 * 2304 * B * 144
+        print(f"batch {B}: MIOpen wgrad {lib:.1f} us = {flop / lib / 1e6:.0f} TFLOP/s")
+        dw = torch.empty((3, 3, 256, 256), dtype=torch.float32, device="cuda")
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for so in sorted(glob.glob(OUT + "/wg_*.so")):
+            L = ctypes.CDLL(so)
+            L.hive_nn_conv3x3_wgrad.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+            ws = torch.empty((L.hive_nn_wgrad_workspace_floats(),), dtype=torch.float32, device="cuda")
+            us = timeit(lambda: L.hive_nn_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, ws.data_ptr(), st))
+            print(f"   {os.path.basename(so):26s} {us:7.1f} us = {flop / us / 1e6:5.0f} TFLOP/s")
+            if hasattr(L, "hive_nn_wgrad_debug_order"):
+                for order in (0, 1):
+                    L.hive_nn_wgrad_debug_order(order)
+                    us = timeit(lambda: L.hive_nn_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, ws.data_ptr(), st))
+                    print(f"      workgroup order {order} ({'slices of a board range on one XCD' if order else 'plain'}): {us:7.1f} us")
+                L.hive_nn_wgrad_debug_order(-1)
