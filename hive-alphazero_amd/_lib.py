@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "hive_batch_illegal_count", "hive_batch_legal", "hive_batch_encode", "hive_batch_terminal",
     "hive_batch_export", "hive_batch_import", "hive_movegen_launch", "hive_encode_launch",
     "hive_terminal_launch", "hive_step_launch", "hive_leaf_launch",
+    "hive_single_create", "hive_single_destroy", "hive_single_advance", "hive_single_encode",
     # include/hive_search.h
     "hive_search_create", "hive_search_destroy", "hive_search_set_stream", "hive_search_set_params",
     "hive_search_set_roots", "hive_search_select", "hive_search_backup", "hive_search_policy",
@@ -92,6 +93,10 @@ def load():
     L.hive_terminal_launch.argtypes = [vp, i32, vp, vp, vp]
     L.hive_step_launch.argtypes = [vp, vp, i32, vp, vp, vp]
     L.hive_leaf_launch.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.hive_single_create.argtypes = [i32, ctypes.POINTER(vp)]
+    L.hive_single_destroy.argtypes = [vp]
+    L.hive_single_advance.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.hive_single_encode.argtypes = [vp, vp, vp, vp]
     L.hive_search_create.argtypes = [i32, i32, i32, i32, ctypes.c_uint64, ctypes.POINTER(vp)]
     L.hive_search_destroy.argtypes = [vp]
     L.hive_search_set_stream.argtypes = [vp, vp]

@@ -1080,6 +1080,126 @@ int hive_batch_import(HiveBatch *h, const HiveBoard *boards, const HiveHistory *
     return HIVE_OK;
 }
 
+// ------------------------------------------------------------------ single-position calls with HOST buffers
+// GamePlay's one-game surface (env_hive.py:99-171,196-304,306-485) without a round trip per question: one call copies
+// the 448-byte position in, runs step -> legal set -> game over as one launch chain on the handle's own stream, copies
+// the answers out and synchronises once.  Device block: [0,64) record, [64,448) history, [448,452) action,
+// [512,776) legal set of the position BEFORE the move (to refuse an illegal action), [1024,1288) legal set after,
+// [1288,1292) count, [1292] over, [1293] winner, [1296,1304) refused-action counter, [2048,3200) packed features,
+// [4096,36352) planes.
+struct HiveSingle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    unsigned char *dev = nullptr;
+    unsigned char *pin = nullptr;       // pinned host mirror of the device block
+};
+static constexpr size_t kSingleBytes = 36352;
+
+int hive_single_destroy(HiveSingle *h);
+
+int hive_single_create(int device, HiveSingle **out)
+{
+    if (out == nullptr) return fail(HIVE_E_ARG, "hive_single_create: out == NULL");
+    *out = nullptr;
+    int cnt = hive_device_count();
+    if (cnt <= 0) return fail(HIVE_E_DEVICE, "hive_single_create: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= cnt) return fail(HIVE_E_ARG, "hive_single_create: bad device ordinal");
+    HIP_TRY(hipSetDevice(device));
+    HiveSingle *h = new (std::nothrow) HiveSingle();
+    if (h == nullptr) return fail(HIVE_E_DEVICE, "hive_single_create: out of host memory");
+    h->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->dev), kSingleBytes);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&h->pin), kSingleBytes, hipHostMallocDefault);
+    if (e == hipSuccess) memset(h->pin, 0, kSingleBytes);
+    if (e == hipSuccess) e = hipMemsetAsync(h->dev, 0, kSingleBytes, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        hive_single_destroy(h);
+        return fail(HIVE_E_DEVICE, std::string("hive_single_create: ") + hipGetErrorString(e));
+    }
+    *out = h;
+    return HIVE_OK;
+}
+
+int hive_single_destroy(HiveSingle *h)
+{
+    if (!h) return HIVE_OK;
+    (void)hipSetDevice(h->device);
+    if (h->dev) (void)hipFree(h->dev);
+    if (h->pin) (void)hipHostFree(h->pin);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return HIVE_OK;
+}
+
+int hive_single_advance(HiveSingle *h, const HiveBoard *rec, const HiveHistory *hist, int action, const uint32_t *legal_before,
+                        HiveBoard *rec_out, HiveHistory *hist_out, uint32_t *legal_after, int32_t *count, int8_t *over,
+                        int8_t *winner)
+{
+    if (!h || !rec_out || !hist_out || !legal_after) return fail(HIVE_E_ARG, "hive_single_advance: null argument");
+    if (action != -3 && (!rec || !hist)) return fail(HIVE_E_ARG, "hive_single_advance: a position is needed unless action == -3");
+    if (action < -3 || action >= HIVE_ACTIONS) return fail(HIVE_E_ARG, "hive_single_advance: action out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    HiveBoard *dboard = reinterpret_cast<HiveBoard *>(h->dev);
+    HiveHistory *dhist = reinterpret_cast<HiveHistory *>(h->dev + 64);
+    int32_t *dact = reinterpret_cast<int32_t *>(h->dev + 448);
+    uint32_t *dmask_in = reinterpret_cast<uint32_t *>(h->dev + 512), *dmask = reinterpret_cast<uint32_t *>(h->dev + 1024);
+    unsigned long long *dill = reinterpret_cast<unsigned long long *>(h->dev + 1296);
+    unsigned long long before = 0;
+    memcpy(&before, h->pin + 1296, sizeof before);          // the counter as of the previous call's copy-out
+    if (action == -3) {
+        hipLaunchKernelGGL(hive_reset_kernel, dim3(1), dim3(64), 0, h->stream, dboard, dhist, 1, (const int32_t *)nullptr, 1);
+    } else {
+        memcpy(h->pin, rec, 64);
+        memcpy(h->pin + 64, hist, 384);
+        memcpy(h->pin + 448, &action, 4);
+        size_t in_bytes = 452;
+        if (action >= 0 && legal_before != nullptr) { memcpy(h->pin + 512, legal_before, 4 * HIVE_MASK_WORDS); in_bytes = 776; }
+        HIP_TRY(hipMemcpyAsync(h->dev, h->pin, in_bytes, hipMemcpyHostToDevice, h->stream));
+        if (action >= 0 && legal_before == nullptr) {       // nobody vouches for the action: derive the legal set first
+            int rc = launch_pieces(dboard, 1, dmask_in, nullptr, nullptr, h->stream);
+            if (rc != HIVE_OK) return rc;
+        }
+        if (action >= -1)
+            hipLaunchKernelGGL(hive_step_kernel, dim3(1), dim3(64), 0, h->stream, dboard, dhist, 1, dact, dmask_in, dill);
+    }
+    HIP_TRY(hipGetLastError());
+    int rc = launch_pieces(dboard, 1, dmask, reinterpret_cast<int32_t *>(h->dev + 1288), nullptr, h->stream);
+    if (rc != HIVE_OK) return rc;
+    hipLaunchKernelGGL(hive_terminal_kernel, dim3(1), dim3(64), 0, h->stream, dboard, 1, reinterpret_cast<int8_t *>(h->dev + 1292),
+                       reinterpret_cast<int8_t *>(h->dev + 1293));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->pin, h->dev, 1304, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    unsigned long long after = 0;
+    memcpy(&after, h->pin + 1296, sizeof after);
+    if (after != before) return fail(HIVE_E_ILLEGAL, "hive_single_advance: the action is not in the legal set; position unchanged");
+    memcpy(rec_out, h->pin, 64);
+    memcpy(hist_out, h->pin + 64, 384);
+    memcpy(legal_after, h->pin + 1024, 4 * HIVE_MASK_WORDS);
+    if (count) memcpy(count, h->pin + 1288, 4);
+    if (over) *over = (int8_t)h->pin[1292];
+    if (winner) *winner = (int8_t)h->pin[1293];
+    return HIVE_OK;
+}
+
+int hive_single_encode(HiveSingle *h, const HiveBoard *rec, const HiveHistory *hist, float *planes)
+{
+    if (!h || !rec || !hist || !planes) return fail(HIVE_E_ARG, "hive_single_encode: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    memcpy(h->pin, rec, 64);
+    memcpy(h->pin + 64, hist, 384);
+    HIP_TRY(hipMemcpyAsync(h->dev, h->pin, 448, hipMemcpyHostToDevice, h->stream));
+    int rc = launch_encode(reinterpret_cast<HiveBoard *>(h->dev), reinterpret_cast<HiveHistory *>(h->dev + 64), 1, h->dev + 4096,
+                           HIVE_F32, HIVE_HWC, reinterpret_cast<unsigned long long *>(h->dev + 2048), h->stream);
+    if (rc != HIVE_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(h->pin + 4096, h->dev + 4096, sizeof(float) * kCells * HIVE_PLANES, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    memcpy(planes, h->pin + 4096, sizeof(float) * kCells * HIVE_PLANES);
+    return HIVE_OK;
+}
+
 #ifdef HIVE_DBG_ITERS
 int hive_debug_iters(unsigned long long *host16)
 {

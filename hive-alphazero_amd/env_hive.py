@@ -4,8 +4,10 @@ Same constructor, methods, attributes and return types, so woker/self_play.py,
 woker/solo_play.py and alpha_zero/MCTS_chess.py can import this class instead.  The rules never
 run in Python: the position lives in a 64-byte HiveBoard record (+ 384-byte history) and every
 move / legal-move / planes / game-over question is answered by the HIP kernels of
-libhive_hip.so through the C ABI.  A GamePlay object keeps only host copies of its own record,
-so copy.deepcopy (solo_play.py:158, MCTS_chess.py:104) is a 448-byte copy.
+libhive_hip.so through the C ABI -- one hive_single_advance call per move (position in, step ->
+legal set -> game over as one launch chain, answers out, one synchronise).  A GamePlay object keeps
+only host copies of its own record, so copy.deepcopy (solo_play.py:158, MCTS_chess.py:104) is a
+copy of ~700 bytes.
 
 For thousands of concurrent games use hive_alphazero_amd.batch.BoardBatch (same kernels, no
 per-call host round trip); this class is the single-game API surface.
@@ -14,11 +16,12 @@ import contextlib
 import copy
 import threading
 
+import ctypes
+
 import numpy as np
 import torch
 
-from . import packing
-from .batch import BoardBatch
+from . import _lib, packing
 from .config import (ACTION_SPACE, MAX_MAP_FULL, PIECE_BLACK, PIECE_KEYS, PIECE_WHITE, SLOT_KEYS, STATE_FEATURES,
                      index_char, index_number)
 
@@ -53,11 +56,46 @@ class _State:
         return 0 if self.turn % 2 == 1 else 1
 
 
+class _Single:
+    """One HiveSingle handle of include/hive_abi.h: a stream, a device block and its pinned host mirror."""
+
+    def __init__(self, dev):
+        self.L = _lib.load()
+        if self.L.hive_device_count() <= 0:
+            raise _lib.HiveError(-2, "no HIP device visible: hive_alphazero_amd has no CPU path")
+        self._h = ctypes.c_void_p()
+        _lib.check(self.L.hive_single_create(int(dev), ctypes.byref(self._h)))
+
+    def advance(self, rec, hist, action, legal_before):
+        """-> (record uint8[64], history uint8[384], legal set uint32[66], over, winner) after `action`
+        (-1 pass, -2 none, -3 new game); raises HiveError(HIVE_E_ILLEGAL) for an action outside legal_before."""
+        rec_out, hist_out = np.empty(64, dtype=np.uint8), np.empty(384, dtype=np.uint8)
+        mask = np.empty(_lib.HIVE_MASK_WORDS, dtype=np.uint32)
+        over, winner = ctypes.c_int8(0), ctypes.c_int8(0)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+        _lib.check(self.L.hive_single_advance(self._h, p(rec), p(hist), int(action), p(legal_before), p(rec_out), p(hist_out), p(mask),
+                                              None, ctypes.byref(over), ctypes.byref(winner)))
+        return rec_out, hist_out, mask, bool(over.value), int(winner.value)
+
+    def encode(self, rec, hist):
+        planes = np.empty((12, 12, STATE_FEATURES), dtype=np.float32)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(self.L.hive_single_encode(self._h, p(rec), p(hist), p(planes)))
+        return planes
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.L.hive_single_destroy(self._h)
+        except Exception:
+            pass
+
+
 class _EnginePool:
-    """Single-board HBM slots of one device.  A GamePlay call borrows a slot for its load -> kernels -> store
-    sequence and hands it back, so concurrent callers (the reference searches with a ThreadPoolExecutor of
-    SEARCH_THREADS = 32 workers, solo_play.py:153-165) never share a slot: a C-ABI handle is not thread-safe
-    (include/hive_abi.h), distinct handles are independent.  At most as many slots exist as callers ever overlapped."""
+    """Single-position handles of one device.  A GamePlay call borrows a handle for its one ABI call and hands it
+    back, so concurrent callers (the reference searches with a ThreadPoolExecutor of SEARCH_THREADS = 32 workers,
+    solo_play.py:153-165) never share one: a C-ABI handle is not thread-safe (include/hive_abi.h), distinct handles are
+    independent.  At most as many handles exist as callers ever overlapped."""
     _inst = {}
     _inst_lock = threading.Lock()
 
@@ -82,16 +120,12 @@ class _EnginePool:
             if b is None:
                 self.created += 1
         if b is None:
-            b = BoardBatch(1, self.dev)
+            b = _Single(self.dev)
         try:
             yield b
         finally:
             with self._lock:
                 self._free.append(b)
-
-
-def _host(t):
-    return t.cpu().numpy()
 
 
 class GamePlay:
@@ -107,19 +141,15 @@ class GamePlay:
         return _EnginePool.get(self._device).slot()
 
     def _advance(self, action):
-        """load -> [step] -> legal -> store in ONE borrowed slot: what the reference recomputes at the end of move()
-        (env_hive.py:169-171: encoded_action; the planes are built lazily)."""
-        with self._slot() as b:
+        """One ABI call: [new game | move | pass] -> record, legal set, game over -- what the reference recomputes at the
+        end of move() (env_hive.py:169-171: encoded_action; the planes are built lazily)."""
+        with self._slot() as h:
             if action is None:
-                b.reset()
+                out = h.advance(None, None, -3, None)
             else:
-                b.import_state(self._rec.reshape(1, 64), self._hist.reshape(1, 384))
-                b.step(np.array([int(action)], dtype=np.int32), sync=True)       # refuses an illegal action (HiveError)
-            mask, _, _ = b.legal()
-            rec, hist = b.export_state()
-            mask, rec, hist = _host(mask), _host(rec), _host(hist)
-        self._rec, self._hist = rec.reshape(64).copy(), hist.reshape(384).copy()
-        self.encoded_action = packing.mask_to_actions(mask.view(np.uint32)[0])
+                out = h.advance(self._rec, self._hist, int(action), self._mask if int(action) >= 0 else None)
+        self._rec, self._hist, self._mask, self._over, self._winner = out
+        self.encoded_action = packing.mask_to_actions(self._mask)
         self._planes = None
         st = packing.unpack_boards(self._rec)
         self._pos, self._lvl = st["pos"][0], st["lvl"][0]
@@ -165,15 +195,12 @@ class GamePlay:
 
     # ------------------------------------------------------------------ reference API
     def game_is_over(self):                  # env_hive.py:58-59, move_checker.py:140-165
-        with self._slot() as b:
-            b.import_state(self._rec.reshape(1, 64), self._hist.reshape(1, 384))
-            over, winner = b.terminal()
-            over, w = bool(over.item()), int(winner.item())
-        if w == 1:
+        # (evaluated by the kernels together with the move that produced this position)
+        if self._winner == 1:
             self.state.winner = PIECE_WHITE
-        elif w == 2:
+        elif self._winner == 2:
             self.state.winner = PIECE_BLACK
-        return over
+        return self._over
 
     def move(self, move, with_skip=False):   # env_hive.py:99-171
         self._advance(move)
@@ -195,9 +222,8 @@ class GamePlay:
         if player != mover:
             raise KeyError(player)           # state_final only holds the mover's planes
         if self._planes is None:
-            with self._slot() as b:
-                b.import_state(self._rec.reshape(1, 64), self._hist.reshape(1, 384))
-                self._planes = b.encode(torch.float32, "hwc").cpu().numpy()[0].astype(np.float64)
+            with self._slot() as h:
+                self._planes = h.encode(self._rec, self._hist).astype(np.float64)
         return self._planes
 
     def turn(self):
@@ -222,6 +248,6 @@ class GamePlay:
         g = GamePlay.__new__(GamePlay)
         g.__dict__.update(self.__dict__)
         g.state = copy.copy(self.state)
-        g._rec, g._hist = self._rec.copy(), self._hist.copy()
+        g._rec, g._hist, g._mask = self._rec.copy(), self._hist.copy(), self._mask.copy()
         g.encoded_action = list(self.encoded_action)
         return g

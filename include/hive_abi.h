@@ -153,6 +153,27 @@ int hive_leaf_launch(const HiveBoard *boards, const HiveHistory *hist, int n, vo
                      HiveLayout layout, void *workspace, uint32_t *mask, int32_t *count, int8_t *over, int8_t *winner,
                      void *stream);
 
+/* ---- One position, HOST buffers: the single-game surface of GamePlay without a round trip per question.
+ * A HiveSingle owns a stream, a device block and a pinned host mirror; a call copies the position in, runs its kernels
+ * as one launch chain, copies the answers out and synchronises once.  Not thread-safe; distinct handles are independent
+ * (hive-alphazero_amd/env_hive.py lends one handle to each concurrent GamePlay call).  All pointers are HOST pointers. */
+typedef struct HiveSingle HiveSingle;
+int hive_single_create(int device, HiveSingle **out);
+int hive_single_destroy(HiveSingle *h);
+
+/* GamePlay.move / skip_turn / new_game + what they recompute (env_hive.py:61-97,99-171,493-496,196-304; game_is_over,
+ * move_checker.py:140-165).  action >= 0: move; -1: pass / skip_turn; -2: no move (only the outputs of `rec`); -3: new
+ * game (rec / hist ignored).  legal_before = the legal set of `rec` as an earlier call returned it (uint32[HIVE_MASK_WORDS],
+ * may be NULL: it is then derived first); an action outside it is refused: HIVE_E_ILLEGAL, outputs untouched.
+ * Outputs: the new record and history, its legal set (destination boards as hive_batch_legal), count, over, winner
+ * (count / over / winner may be NULL). */
+int hive_single_advance(HiveSingle *h, const HiveBoard *rec, const HiveHistory *hist, int action, const uint32_t *legal_before,
+                        HiveBoard *rec_out, HiveHistory *hist_out, uint32_t *legal_after, int32_t *count, int8_t *over,
+                        int8_t *winner);
+
+/* GamePlay.encode_board (env_hive.py:306-485): planes = float[12][12][56] (HWC, the reference's layout) of the mover's side. */
+int hive_single_encode(HiveSingle *h, const HiveBoard *rec, const HiveHistory *hist, float *planes);
+
 #ifdef __cplusplus
 }
 #endif
