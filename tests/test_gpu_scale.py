@@ -330,3 +330,29 @@ def test_facade_single_move_latency():
         json.dump(med, f)
     print("facade latency (median us):", med)
     assert med["move_us"] < 5000
+
+
+def test_selfplay_worker_real_children_on_the_gpu(tmp_path):
+    """SURVEY 8e end to end with the REAL producer: SelfPlayWorker spawns two children (both on this box's one GPU, each
+    with HIP_VISIBLE_DEVICES set before it starts), every child builds the network, plays its shard of the global game ids
+    in lock step on the GPU and streams finished games back; the parent ends up with every game exactly once, ordered by
+    id, as reference-format rows, plus the files it flushed."""
+    from hive_alphazero_amd.self_play import SelfPlayWorker
+    lines = []
+    w = SelfPlayWorker(total_games=6, games_per_gpu=4, sims=3, gpus=[0, 0], seed=5, datapath=str(tmp_path), games_per_file=4,
+                       report_every=2, log=lines.append)
+    res = w.start(timeout_s=600)
+    assert list(res) == [0, 1, 2, 3, 4, 5]
+    for gid, (value_white, rows) in res.items():
+        assert value_white in (-1, 0, 1) and 7 <= len(rows) <= 54
+        counters = {"W": 0, "B": 0}
+        for k, (state, policy, value, lens) in enumerate(rows):
+            side = "W" if k % 2 == 0 else "B"                     # nobody passes this early with every piece in hand
+            counters[side] += 1
+            assert np.asarray(state).shape == (12, 12, 56) and len(policy) == 1584
+            assert abs(sum(policy) - 1.0) < 1e-3 or sum(policy) == 0
+            assert value == (-1 if value_white == 0 else (value_white if side == "W" else -value_white))
+            assert lens[1] == counters[side]
+        assert rows[0][0][0][0][31] == 1 and rows[1][0][0][0][31] == 2           # plane 31 = the raw turn number
+    assert len(lines) == 3 and len(w.files) == 2
+    assert w.leaf_kinds["root_evaluated"] >= sum(len(r) for _, r in res.values())
