@@ -584,36 +584,51 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
 }
 
 // GamePlay.encode_action (env_hive.py:287-304): {slot: destination board} -> ascending action ids.
-// One wave per board: lane l of pass t asks "is action 64 t + l legal?" of the destination boards held
-// in LDS; the ballot of the answers is the id-ordered mask word, v_mbcnt gives each lane its list slot.
+// One wave per board.  Action id = cell * 11 + slot, so ascending ids = cells in order, slots in order inside a cell:
+// lane l of pass t (three passes cover the 144 cells) gathers the 11 slot bits of cell 64 t + l from the destination
+// boards held in LDS, a wave prefix sum of the popcounts gives every cell its place in the list, the ids are laid down in
+// an LDS row and leave as one coalesced 8-byte store per lane (-1 padded).
 __global__ void __launch_bounds__(256)
 hive_list_kernel(const uint32_t *__restrict__ mask, int n, int16_t *__restrict__ list)
 {
     __shared__ uint32_t dest[4][HIVE_MASK_WORDS + 2];
+    __shared__ __attribute__((aligned(8))) int16_t rowbuf[4][HIVE_LIST_CAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long b = (long long)blockIdx.x * 4 + wv;
     if (b >= n) return;
     const uint32_t *m = mask + b * HIVE_MASK_WORDS;
     dest[wv][lane] = m[lane];
     if (lane < HIVE_MASK_WORDS - 64) dest[wv][64 + lane] = m[64 + lane];
+    reinterpret_cast<unsigned long long *>(rowbuf[wv])[lane] = 0xFFFFFFFFFFFFFFFFull;      // four -1 entries per lane
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // same-wave LDS traffic only: program order suffices
     __builtin_amdgcn_wave_barrier();
-    int16_t *row = list + b * HIVE_LIST_CAP;
     int total = 0;
-    for (int t = 0; t < 25; ++t) {
-        const unsigned a = 64u * (unsigned)t + (unsigned)lane;
-        const unsigned cell = a / 11u, slot = a - cell * 11u;
-        unsigned wi, bit;
-        cell_word_bit(cell, wi, bit);
-        const bool legal = a < (unsigned)HIVE_ACTIONS && ((dest[wv][slot * 6u + wi] >> bit) & 1u);
-        const unsigned long long w = __ballot(legal);
-        if (legal) {
-            int p = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(w >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)w, 0u));
-            if (p < HIVE_LIST_CAP) row[p] = (int16_t)a;
+    for (int t = 0; t < 3; ++t) {
+        const unsigned cell = 64u * (unsigned)t + (unsigned)lane;
+        unsigned bits = 0u;
+        if (cell < (unsigned)kCells) {
+            unsigned wi, bit;
+            cell_word_bit(cell, wi, bit);
+            HIVE_UNROLL for (unsigned s = 0; s < 11u; ++s) bits |= ((dest[wv][s * 6u + wi] >> bit) & 1u) << s;
         }
-        total += __popcll(w);
+        const int cnt = __popc(bits);
+        int incl = cnt;                                         // inclusive prefix sum over the wave
+        HIVE_UNROLL for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        int pos = total + incl - cnt;
+        while (bits) {                                          // this cell's legal slots in ascending order
+            const unsigned s = (unsigned)__builtin_ctz(bits);
+            bits &= bits - 1u;
+            if (pos < HIVE_LIST_CAP) rowbuf[wv][pos] = (int16_t)(cell * 11u + s);
+            ++pos;
+        }
+        total += __shfl(incl, 63);
     }
-    for (int p = total + lane; p < HIVE_LIST_CAP; p += 64) row[p] = -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    reinterpret_cast<unsigned long long *>(list + b * HIVE_LIST_CAP)[lane] = reinterpret_cast<const unsigned long long *>(rowbuf[wv])[lane];
 }
 
 // value encoders for the plane writer
