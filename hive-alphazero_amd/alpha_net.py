@@ -405,6 +405,7 @@ class InferenceNet:
         for name, value in self._folded(net.eval()).items():
             setattr(self, name, value)
         self._graphs = {}
+        self._tunable_before = None        # TunableOp's process-wide switch as it was before this object turned it on
         import threading
         self._lock = threading.Lock()      # capture/replay share static buffers: one caller at a time
 
@@ -525,7 +526,9 @@ class InferenceNet:
         if not tn.is_enabled():
             # the results file TunableOp writes at exit goes to the temp directory, not into the caller's cwd
             tn.set_filename(os.path.join(tempfile.gettempdir(), "hive_tunableop_%d.csv" % os.getpid()))
-        tn.enable(True)                    # stays on: the recorded solutions are what later calls (and the graph) use
+        if self._tunable_before is None:
+            self._tunable_before = bool(tn.is_enabled())
+        tn.enable(True)                    # on until the graph of this batch size is captured (it keeps the solutions picked)
         tn.set_max_tuning_duration(1000)
         tn.tuning_enable(True)
         try:
@@ -562,6 +565,12 @@ class InferenceNet:
                 out = self._forward(static_in)
             g = (graph, static_in, out)
             self._graphs[B] = g
+            if self._tunable_before is not None:
+                # TunableOp is process-global: left on, every later GEMM of the process (a training step in the same
+                # process ran 25.9 instead of 16.6 ms) goes through it; the captured graph does not need it any more
+                import torch.cuda.tunable as tn
+                tn.enable(self._tunable_before)
+                self._tunable_before = None
         graph, static_in, out = g
         static_in.copy_(planes_hwc)
         graph.replay()
