@@ -198,12 +198,14 @@ def training_measure(steps, batch=512):
     for _ in range(5):                          # the libraries' first-call searches (stem / head convolutions) end here
         tr.step(x, pi, z)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    per_step = []
     for _ in range(steps):
-        loss = tr.step(x, pi, z)
-    torch.cuda.synchronize()
-    el = (time.perf_counter() - t0) / steps
+        t0 = time.perf_counter()
+        loss = tr.step(x, pi, z)                # (returns the loss as a float: one synchronise per step, like the reference's loop)
+        per_step.append(time.perf_counter() - t0)
+    el = sorted(per_step)[len(per_step) // 2]   # median: a single allocator / garbage-collection hiccup is not the step
     return {"workload": f"train_step_batch{batch}", "ms_per_step": round(el * 1e3, 2), "positions_per_s": round(batch / el, 1),
+            "ms_per_step_mean": round(sum(per_step) / len(per_step) * 1e3, 2), "ms_per_step_max": round(max(per_step) * 1e3, 2),
             "TFLOPs_fwd_bwd_as_3x_fwd": round(3 * GFLOP_PER_LEAF * batch / el / 1e3, 1), "dtype": "bf16 (fp32 master weights)",
             "fused_hip_kernels": bool(tr.fused), "loss": round(float(loss), 4)}
 
@@ -433,6 +435,10 @@ def main():
 
     training = None
     if world == 1 and args.train_steps > 0:                   # single-GPU side measurement (no DDP group to join)
+        import gc
+        gc.collect()                                          # the self-play engines, their graphs and pools are gone for good
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
         try:
             training = training_measure(args.train_steps)
         except Exception as exc:                 # a side measurement never takes the headline line down
