@@ -454,6 +454,13 @@ def test_inference_net_refresh_keeps_graphs_and_takes_new_weights():
     fresh_p, fresh_v = InferenceNet(net_b)(x)
     assert torch.equal(pb, fresh_p) and torch.equal(vb, fresh_v)
     assert (pa - pb).abs().max().item() > 1e-5                  # and it is not the old network any more
+    # a large batch lets TunableOp pick the head GEMMs before the capture -- and hands the process-wide switch back
+    import torch.cuda.tunable as tn
+    was = tn.is_enabled()
+    big = (torch.rand((256, 12, 12, 56), device="cuda") < 0.1).to(torch.bfloat16)
+    p256, _ = inf(big)
+    assert tn.is_enabled() == was and 256 in inf._graphs
+    assert float((p256.sum(1) - 1).abs().max().item()) < 1e-3
 
 
 def test_train_matches_reference_training_run_cpu():
