@@ -18,21 +18,19 @@ from .alpha_net import InferenceNet
 class HiveModelAPI:
     def __init__(self, agent_model):
         self.agent_model = agent_model
-        self.pipes = []
-        self._running = True
+        self.pipes = []                 # server ends, one per client (the reference keeps them under this name too)
+        self._serving = True
 
     def start(self):
-        worker = Thread(target=self._predict_batch_worker, name="prediction_worker")
-        worker.daemon = True
-        worker.start()
+        Thread(target=self._serve, name="prediction_worker", daemon=True).start()
 
     def create_pipe(self):
-        me, you = Pipe()
-        self.pipes.append(me)
-        return you
+        server_end, client_end = Pipe()
+        self.pipes.append(server_end)
+        return client_end
 
     def stop(self):
-        self._running = False
+        self._serving = False
 
     def _forward(self, batch_hwc):
         m = self.agent_model
@@ -44,29 +42,32 @@ class HiveModelAPI:
                 p, v = m(torch.from_numpy(np.ascontiguousarray(batch_hwc.transpose(0, 3, 1, 2))).to(dev))
         return p.detach().float().cpu().numpy(), v.detach().float().cpu().numpy().reshape(-1)
 
-    def _predict_batch_worker(self):
-        while self._running:
+    @staticmethod
+    def _drain(ends):
+        """Every request waiting on the readable ends: ([planes float32[12,12,56]], [the end to answer on])."""
+        planes, owners = [], []
+        for end in ends:
+            while end.poll():
+                planes.append(np.asarray(end.recv(), dtype=np.float32))
+                owners.append(end)
+        return planes, owners
+
+    def _serve(self):
+        """Block until some client has sent planes, evaluate everything that is waiting in ONE forward, answer each
+        client with (p[1584], float v) -- api_hive.py:47-74, which polls every millisecond instead."""
+        while self._serving:
             try:
-                ready = connection.wait(self.pipes, timeout=0.05)
+                readable = connection.wait(self.pipes, timeout=0.05)
+                planes, owners = self._drain(readable) if readable else ([], [])
             except (OSError, EOFError, ValueError):      # the clients closed their ends: stop serving
                 return
-            if not ready:
-                continue
-            data, result_pipes = [], []
-            try:
-                for pipe in ready:
-                    while pipe.poll():
-                        data.append(np.asarray(pipe.recv(), dtype=np.float32))
-                        result_pipes.append(pipe)
-            except (OSError, EOFError):
-                return
-            if not data:
+            if not planes:
                 continue
             try:
-                policy_ary, value_ary = self._forward(np.stack(data))
+                policies, values = self._forward(np.stack(planes))
             except Exception as exc:          # keep serving: a failed batch answers with the exception
-                for pipe in result_pipes:
-                    pipe.send(exc)
+                for end in owners:
+                    end.send(exc)
                 continue
-            for pipe, p, v in zip(result_pipes, policy_ary, value_ary):
-                pipe.send((p, float(v)))
+            for end, p, v in zip(owners, policies, values):
+                end.send((p, float(v)))
