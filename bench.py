@@ -21,10 +21,10 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_BOARD = 262          # 64 B HiveBoard read + 198 B (1584-bit) legal mask written, SURVEY.md 8d
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
-# HBM bytes per board from the PMC passes in profiles/r01_movegen_pmc_traffic.md: (2 x FETCH_SIZE + WRITE_SIZE) KiB
-# per 4096-board launch = 1,614,848 B (gfx950 FETCH_SIZE correction applied); not measurable from inside bench.py
-MOVEGEN_TRAFFIC_BYTES_PER_BOARD = 394
-MOVEGEN_TRAFFIC_SOURCE = "profiles/r01_movegen_pmc_traffic.md (separate rocprofv3 --pmc passes of this command; not measured in-run)"
+# HBM bytes per board from the PMC passes in profiles/r02_movegen_pmc_traffic.md: (2 x FETCH_SIZE + WRITE_SIZE) KiB
+# per 4096-board launch = 1,622,036 B (gfx950 FETCH_SIZE correction applied); not measurable from inside bench.py
+MOVEGEN_TRAFFIC_BYTES_PER_BOARD = 396
+MOVEGEN_TRAFFIC_SOURCE = "profiles/r02_movegen_pmc_traffic.md (separate rocprofv3 --pmc passes of this command; not measured in-run)"
 # the bound that actually binds: 489 VALU wave-instructions per board (PMC, profiles/r01_movegen_pmc_valu.md), each
 # occupying one of the 1024 SIMDs for 4 cycles at 2.4 GHz
 MOVEGEN_VALU_PER_BOARD = 489
@@ -471,7 +471,8 @@ def main():
                          "kernel": "hive_piece_kernel<false>", "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_BOARD,
                          "note": "VALU-issue bound (489 wave-instructions per board), not HBM bound: see saturated.valu_issue_roof; "
-                                 "4096 boards = 256 workgroups x 11 waves = one workgroup per CU"},
+                                 "4096 boards = 256 workgroups x 11 waves = one workgroup per CU; the 256 KB corpus is re-read "
+                                 "every step, so the read side is served by L2 / Infinity Cache and the HBM label is nominal"},
             "movegen_with_sorted_id_list": with_list,
             "overlapped_4_streams": overlapped,
             "saturated": sat,
