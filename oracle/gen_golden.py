@@ -280,11 +280,18 @@ def cmd_uct(a):
     (UCT_search itself hard-codes .cuda() at :138, so its five-line loop is restated here)."""
     from alpha_zero.MCTS_chess import UCTNode, DummyNode
     cases = []
-    for ci, pre_plies in enumerate([0, 3, 11, 22]):
-        rng = np.random.default_rng(300 + ci)
+    plan = [(300 + ci, pp) for ci, pp in enumerate([0, 3, 11, 22])]
+    out_name = "uct.json"
+    if getattr(a, "deep", False):          # later positions, more reads: deeper trees, finished games inside the tree
+        plan = [(340 + ci, pp) for ci, pp in enumerate([30, 38, 44, 48, 51])]
+        out_name = "uct_deep.json"
+    for ci, (seed, pre_plies) in enumerate(plan):
+        rng = np.random.default_rng(seed)
         g = _new_game()
         prefix = []
         for _ in range(pre_plies):
+            if g.game_is_over() or not g.actions():
+                break
             act = choose(g, rng, "uniform")
             prefix.append(act)
             g.move(act)
@@ -301,7 +308,7 @@ def cmd_uct(a):
         cases.append({"prefix": prefix, "reads": a.reads, "best": int(np.argmax(root.child_number_visits)),
                       "visits": [[int(i), float(root.child_number_visits[i]), float(root.child_total_value[i])] for i in nz]})
         print("uct case", ci, cases[-1]["best"], len(nz), flush=True)
-    with open(os.path.join(GOLD, "uct.json"), "w") as f:
+    with open(os.path.join(GOLD, out_name), "w") as f:
         json.dump({"cases": cases}, f, separators=(",", ":"))
 
 
@@ -524,6 +531,7 @@ if __name__ == "__main__":
     pn.add_argument("--seed", type=int, default=0)
     pu = sub.add_parser("uct")
     pu.add_argument("--reads", type=int, default=40)
+    pu.add_argument("--deep", action="store_true", help="write uct_deep.json: late positions (use --reads 120)")
     ps = sub.add_parser("selfplay")
     ps.add_argument("--sims", type=int, default=5)
     ps.add_argument("--seed", type=int, default=4)

@@ -112,13 +112,15 @@ def test_records_wire_format(tmp_path, golden_games):
     assert back[0][2] == pytest.approx(1 * 0.99 ** (2 - 1)) and back[2][2] == 1     # optimize.py:55-58
 
 
-def test_uct_restatement_matches_reference():
+@pytest.mark.parametrize("fixture", ["uct.json", "uct_deep.json"])
+def test_uct_restatement_matches_reference(fixture):
     """tests/uct_ref.py (the checker the GPU tests hold the HIVE_SEARCH_UCT kernels against) reproduces the TRUE reference's
-    UCTNode search (tests/golden/uct.json, oracle/gen_golden.py uct): visits, total values and the chosen move."""
+    UCTNode search (oracle/gen_golden.py uct [--deep]): visits, total values and the chosen move -- 40 reads from early
+    positions, 120 reads from late ones (deeper trees, finished games inside the tree, a finished game as the root)."""
     from mcts_stub import stub_predict
     from oracle_env import OracleGamePlay
     from uct_ref import uct_reads
-    with open(os.path.join(GOLD, "uct.json")) as f:
+    with open(os.path.join(GOLD, fixture)) as f:
         gold = json.load(f)
     for case in gold["cases"]:
         g = OracleGamePlay()
