@@ -312,12 +312,7 @@ class SelfPlay:
     def game_rows(entry):
         """One finished game as the reference's JSON rows [state, policy, value, [game_len, counter]]."""
         from . import records
-        vw, plies = entry[0], entry[1]
-        expanded = []
-        for words, hist, hlen, turn, policy, mover in plies:
-            hp = records.history_planes(hist, hlen)
-            expanded.append((records.unpack_features(words, turn, hp), policy, "W" if mover == 0 else "B"))
-        return records.game_entries(expanded, vw)
+        return records.rows_from_game(entry)
 
     def finished_game_rows(self, k):
         """The k-th waiting finished game as the reference's rows."""

@@ -1,10 +1,15 @@
-"""Self-play records in the reference's wire format (first "next" row).
+"""Self-play records in the reference's wire format (first "next" row) and in a compact one.
 
 woker/self_play.py:100-112,178-193 writes `play_<ts>.json` = list of
 `[state[12][12][56], policy[1584], value, [game_len, counter]]`; woker/optimize.py:42-65 loads it
 and applies `value * 0.99 ** (game_len - step)`.  The GPU engine keeps, per ply, the packed 56-bit
 features of every game (1,152 B instead of the 64 KB float64 planes), the visit policy and the mover;
 this module expands finished games into those entries.
+
+One MI355X plays ~4,000 games/min = ~3,400 rows/s; as JSON that is ~13 GB/min of text (8,064 numbers per row), more than
+Python can format.  `save_games / load_games` therefore keep finished games as they leave the GPU -- packed features,
+history bitboards, sparse visit policy: ~1.5 KB per row in an .npz -- and `dataset_from_games` / `rows_from_game` expand
+them into exactly what the JSON route yields (same planes, same discounted values) when the trainer asks.
 """
 import json
 import os
@@ -81,3 +86,74 @@ def load_data(filename):                     # woker/optimize.py:42-65
             value = value * DISCOUNTED_REWARD ** (game_len - step)
         rows.append([np.array(state), np.array(policy, dtype=np.float32), value])
     return rows
+
+
+# ------------------------------------------------------------------ compact game files
+def rows_from_game(entry):
+    """One finished game (value_white, plies[, game id]) as SelfPlay collects it -> the reference's rows."""
+    expanded = []
+    for words, hist, hlen, turn, policy, mover in entry[1]:
+        expanded.append((unpack_features(words, turn, history_planes(hist, hlen)), policy, "W" if mover == 0 else "B"))
+    return game_entries(expanded, entry[0])
+
+
+def save_games(path, games):
+    """Finished games (SelfPlay.finished_games / drain_finished entries) -> one compressed .npz, ~1.5 KB per row."""
+    feat, hist, meta, pol_idx, pol_val, pol_ptr, game_ptr, game_val, game_id = [], [], [], [], [], [0], [0], [], []
+    for entry in games:
+        for words, hw, hlen, turn, policy, mover in entry[1]:
+            feat.append(np.asarray(words, dtype=np.uint64).reshape(144))
+            hist.append(np.asarray(hw, dtype=np.uint32).reshape(4, 2, 6))
+            meta.append((int(hlen), int(turn), int(mover)))
+            nz = np.flatnonzero(policy)
+            pol_idx.append(nz.astype(np.int16))
+            pol_val.append(np.asarray(policy, dtype=np.float32)[nz])
+            pol_ptr.append(pol_ptr[-1] + len(nz))
+        game_ptr.append(len(feat))
+        game_val.append(int(entry[0]))
+        game_id.append(int(entry[2]) if len(entry) > 2 else -1)
+    np.savez_compressed(
+        path, feat=np.stack(feat) if feat else np.zeros((0, 144), np.uint64),
+        hist=np.stack(hist) if hist else np.zeros((0, 4, 2, 6), np.uint32), meta=np.asarray(meta, dtype=np.uint8).reshape(-1, 3),
+        pol_idx=np.concatenate(pol_idx) if pol_idx else np.zeros(0, np.int16),
+        pol_val=np.concatenate(pol_val) if pol_val else np.zeros(0, np.float32), pol_ptr=np.asarray(pol_ptr, dtype=np.int64),
+        game_ptr=np.asarray(game_ptr, dtype=np.int64), game_val=np.asarray(game_val, dtype=np.int8),
+        game_id=np.asarray(game_id, dtype=np.int64))
+    return path
+
+
+def load_games(path):
+    """Inverse of save_games: list of (value_white, plies, game id) with plies as SelfPlay.ply_record builds them."""
+    with np.load(path) as z:                      # plain arrays only: nothing in the file is executed
+        feat, hist, meta = z["feat"], z["hist"], z["meta"]
+        pol_idx, pol_val, pol_ptr = z["pol_idx"], z["pol_val"], z["pol_ptr"]
+        game_ptr, game_val, game_id = z["game_ptr"], z["game_val"], z["game_id"]
+    games = []
+    for g in range(len(game_val)):
+        plies = []
+        for r in range(int(game_ptr[g]), int(game_ptr[g + 1])):
+            policy = np.zeros(1584, dtype=np.float32)
+            lo, hi = int(pol_ptr[r]), int(pol_ptr[r + 1])
+            policy[pol_idx[lo:hi]] = pol_val[lo:hi]
+            plies.append((feat[r], hist[r], int(meta[r, 0]), int(meta[r, 1]), policy, int(meta[r, 2])))
+        games.append((int(game_val[g]), plies, int(game_id[g])))
+    return games
+
+
+def dataset_from_games(games):
+    """What woker/optimize.py:42-65 builds from the JSON rows, straight from compact games: (states float32 [N,12,12,56],
+    policies float32 [N,1584], values float32 [N]) with value * 0.99 ** (game_len - step) applied."""
+    states, policies, values = [], [], []
+    for entry in games:
+        vw, plies = entry[0], entry[1]
+        total = [sum(1 for p in plies if p[5] == s) for s in (0, 1)]
+        seen = [0, 0]
+        for words, hw, hlen, turn, policy, mover in plies:
+            seen[mover] += 1
+            value = -1.0 if vw == 0 else float(vw if mover == 0 else -vw)
+            if seen[mover] != total[mover]:
+                value = value * DISCOUNTED_REWARD ** (total[mover] - seen[mover])
+            states.append(unpack_features(words, turn, history_planes(hw, hlen)).astype(np.float32))
+            policies.append(np.asarray(policy, dtype=np.float32))
+            values.append(value)
+    return np.stack(states), np.stack(policies), np.asarray(values, dtype=np.float32)

@@ -39,7 +39,9 @@ def _game_worker(rank, world, cfg, out):
         while True:
             sp.play_ply()
             for entry in sp.drain_finished():
-                out.put(("game", rank, entry[2], entry[0], mcts.SelfPlay.game_rows(entry)))
+                # "json": the reference's rows (lists of 8,064 numbers per row: fine for a few hundred games); "compact": the
+                # game as it left the GPU (packed features, sparse policy), expanded only when somebody asks
+                out.put(("game", rank, entry[2], entry[0], mcts.SelfPlay.game_rows(entry) if cfg["row_format"] == "json" else entry))
             if sp.running() == 0:
                 break
         illegal, leaves = sp.env.illegal_count(), sp.leaf_histogram()
@@ -52,9 +54,15 @@ def _game_worker(rank, world, cfg, out):
 
 class SelfPlayWorker:
     def __init__(self, total_games, games_per_gpu=1024, sims=50, gpus=None, seed=0, net_seed=0, checkpoint=None, slots=1,
-                 datapath="../dataSelf", games_per_file=100, report_every=10, worker=_game_worker, log=print):
+                 datapath="../dataSelf", games_per_file=100, report_every=10, worker=_game_worker, log=print, row_format="json"):
+        """row_format "json": results / files hold the reference's rows (play_<ts>.json, self_play.py:100-112);
+        "compact": results hold the games as SelfPlay collects them and the files are play_<ts>.npz (records.save_games;
+        records.dataset_from_games / rows_from_game expand them) -- the format that keeps up with a node of GPUs."""
+        if row_format not in ("json", "compact"):
+            raise ValueError("row_format must be 'json' or 'compact'")
+        self.row_format = row_format
         self.cfg = {"total_games": int(total_games), "games_per_gpu": int(games_per_gpu), "sims": int(sims), "seed": int(seed),
-                    "net_seed": int(net_seed), "checkpoint": checkpoint, "slots": int(slots)}
+                    "net_seed": int(net_seed), "checkpoint": checkpoint, "slots": int(slots), "row_format": row_format}
         if gpus is None:
             import torch
             gpus = list(range(torch.cuda.device_count()))      # counting devices does not initialise HIP
@@ -88,10 +96,14 @@ class SelfPlayWorker:
         return procs
 
     def _take(self, game_id, value_white, rows):
-        self.results[game_id] = (value_white, rows)
+        compact = self.row_format == "compact"
+        self.results[game_id] = rows if compact else (value_white, rows)        # compact: the whole (value, plies, id) entry
         self.win_lose.append(value_white)
-        self.game_lens.append(len(rows))
-        self.buffer += rows
+        self.game_lens.append(len(rows[1]) if compact else len(rows))
+        if compact:
+            self.buffer.append(rows)
+        else:
+            self.buffer += rows
         n = len(self.win_lose)
         if self.games_per_file and n % self.games_per_file == 0:
             self.flush_buffer()
@@ -102,7 +114,13 @@ class SelfPlayWorker:
 
     def flush_buffer(self):
         if self.buffer and self.datapath:
-            self.files.append(records.flush_buffer(self.buffer, self.datapath))
+            if self.row_format == "compact":
+                import datetime
+                os.makedirs(self.datapath, exist_ok=True)
+                name = "play_%s.npz" % datetime.datetime.now().strftime("%Y%m%d-%H%M%S.%f")
+                self.files.append(records.save_games(os.path.join(self.datapath, name), self.buffer))
+            else:
+                self.files.append(records.flush_buffer(self.buffer, self.datapath))
         self.buffer = []
 
     def start(self, timeout_s=None):

@@ -412,3 +412,27 @@ def test_noisy_search_follows_the_sequential_reference_process_in_distribution()
     top = int(np.bincount(np.asarray(ra), minlength=1584).argmax())
     fg, fr = float((ga == top).mean()), float((np.asarray(ra) == top).mean())
     assert abs(fg - fr) < 4.5 * np.sqrt(fg * (1 - fg) / G + fr * (1 - fr) / R) + 0.02, (fg, fr)
+
+
+def test_selfplay_worker_compact_game_files(tmp_path):
+    """The format that keeps up with the GPU: row_format="compact" keeps finished games as they leave the device (packed
+    features, history bitboards, sparse policy; ~1.5 KB per row instead of ~32 KB of JSON text) and writes play_<ts>.npz;
+    expanding them gives the same kind of rows the JSON route gives, and the trainer's arrays directly."""
+    from hive_alphazero_amd import records
+    from hive_alphazero_amd.self_play import SelfPlayWorker
+    w = SelfPlayWorker(total_games=4, games_per_gpu=4, sims=3, gpus=[0], seed=5, datapath=str(tmp_path), games_per_file=2,
+                       report_every=0, row_format="compact")
+    res = w.start(timeout_s=600)
+    assert list(res) == [0, 1, 2, 3] and len(w.files) == 2 and all(f.endswith(".npz") for f in w.files)
+    loaded = [g for f in w.files for g in records.load_games(f)]
+    assert sorted(g[2] for g in loaded) == [0, 1, 2, 3]
+    by_id = {g[2]: g for g in loaded}
+    n_rows = 0
+    for gid, entry in res.items():
+        rows = records.rows_from_game(entry)
+        assert json.dumps(rows) == json.dumps(records.rows_from_game(by_id[gid]))
+        assert np.asarray(rows[0][0]).shape == (12, 12, 56) and rows[0][0][0][0][31] == 1
+        n_rows += len(rows)
+    states, policies, values = records.dataset_from_games(loaded)
+    assert states.shape == (n_rows, 12, 12, 56) and policies.shape == (n_rows, 1584) and values.shape == (n_rows,)
+    assert sum(os.path.getsize(f) for f in w.files) < 4000 * n_rows

@@ -256,3 +256,36 @@ def test_selfplay_worker_shards_games_by_global_id(tmp_path):
         runs[len(gpus)] = res
     assert runs[1] == runs[2]
     assert "HIP_VISIBLE_DEVICES" not in os.environ or os.environ["HIP_VISIBLE_DEVICES"] != "1"
+
+
+def test_compact_game_files_expand_to_the_reference_rows(tmp_path):
+    """records.save_games / load_games keep finished games as they leave the GPU (packed 56-bit features, history bitboards,
+    sparse policy); rows_from_game and dataset_from_games must yield exactly what the JSON route (game_entries ->
+    flush_buffer -> load_data = woker/optimize.py:42-65) yields: same planes, same policies, same discounted values."""
+    from hive_alphazero_amd import records
+    rng = np.random.default_rng(0)
+    games = []
+    for gid, (vw, n) in enumerate(((1, 7), (0, 4), (-1, 9))):
+        plies = []
+        for k in range(n):
+            words = rng.integers(0, 1 << 56, size=144, dtype=np.uint64) & ~np.uint64(1 << 31) & ~np.uint64(0xFF << 36)
+            hist = rng.integers(0, 1 << 12, size=(4, 2, 6), dtype=np.uint32)
+            policy = np.zeros(1584, dtype=np.float32)
+            idx = rng.choice(1584, size=int(rng.integers(1, 40)), replace=False)
+            policy[idx] = rng.random(len(idx)).astype(np.float32)
+            policy /= policy.sum()
+            plies.append((words, hist, min(k // 2, 4), k + 1, policy, k % 2))
+        games.append((vw, plies, 100 + gid))
+    path = records.save_games(str(tmp_path / "play.npz"), games)
+    assert os.path.getsize(path) < 3000 * sum(len(g[1]) for g in games)
+    back = records.load_games(path)
+    assert [(g[0], len(g[1]), g[2]) for g in back] == [(g[0], len(g[1]), g[2]) for g in games]
+    rows = [r for g in games for r in records.rows_from_game(g)]
+    rows_back = [r for g in back for r in records.rows_from_game(g)]
+    assert json.dumps(rows) == json.dumps(rows_back)
+    json_path = records.flush_buffer(rows, str(tmp_path))
+    via_json = records.load_data(json_path)                 # [state, policy, discounted value] per row
+    states, policies, values = records.dataset_from_games(back)
+    assert len(via_json) == len(states) == 20
+    for (s, p, v), s2, p2, v2 in zip(via_json, states, policies, values):
+        assert np.array_equal(s.astype(np.float32), s2) and np.array_equal(p, p2) and abs(v - v2) < 1e-6
