@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib, packing
-from .config import (ACTION_SPACE, MAX_MAP_FULL, PIECE_BLACK, PIECE_KEYS, PIECE_WHITE, SLOT_KEYS, STATE_FEATURES,
+from .config import (MAX_MAP_FULL, PIECE_BLACK, PIECE_KEYS, PIECE_WHITE, SLOT_KEYS, STATE_FEATURES,
                      index_char, index_number)
 
 # state.board_tiles order (tile.py:180-198): rows 11 -> 0, columns 0 -> 11
