@@ -141,7 +141,7 @@ conv3x3_wgrad_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ DY
             for (int c = 0; c < 2; ++c) acc[t][a][c] = wf32x4{0.f, 0.f, 0.f, 0.f};
 
     // the MFMA work on one staged board
-    // ... during which two spans of the NEXT board (nb >= 0) are sent off per k-step: ten LDS-DMA instructions issued
+    // ... during which the spans of the NEXT board (nb >= 0) are sent off a few per k-step: ten LDS-DMA instructions issued
     // back to back at the board boundary would stall both waves of a SIMD at the same moment
     auto board_mfma = [&](const unsigned char *dyi, int nb, unsigned char *nimage) {
         const unsigned char *xi = dyi + kWgDyBytes;
@@ -149,8 +149,19 @@ conv3x3_wgrad_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ DY
         for (int s = 0; s < 5; ++s) {
 #ifndef HIVE_WG_ABL_NOSTAGE
             if (nb >= 0) {
+#ifdef HIVE_WG_EARLY_DMA
+                // (experiment: three spans per k-step in the first three k-steps, none in the last -- measured 3 % slower)
+                if (s < 4) {
+                    stage_span(nb, nimage, 3 * s);
+                    if (s < 3) {
+                        stage_span(nb, nimage, 3 * s + 1);
+                        stage_span(nb, nimage, 3 * s + 2);
+                    }
+                }
+#else
                 stage_span(nb, nimage, 2 * s);
                 stage_span(nb, nimage, 2 * s + 1);
+#endif
             }
 #endif
             // this lane's pixel rows: k-group grp holds pixels 32 s + 4 grp + {0..3} (first read) and + 16 (second read);
