@@ -436,3 +436,63 @@ def test_selfplay_worker_compact_game_files(tmp_path):
     states, policies, values = records.dataset_from_games(loaded)
     assert states.shape == (n_rows, 12, 12, 56) and policies.shape == (n_rows, 1584) and values.shape == (n_rows,)
     assert sum(os.path.getsize(f) for f in w.files) < 4000 * n_rows
+
+
+def test_facade_refuses_illegal_moves_and_keeps_its_state():
+    """GamePlay.move of an action outside the legal set: HIVE_E_ILLEGAL from hive_single_advance, the position, its legal list
+    and state_key untouched (the reference applies such a move blindly, env_hive.py:129-144); the handle stays usable."""
+    from hive_alphazero_amd import HiveError
+    from hive_alphazero_amd.env_hive import GamePlay
+    g = GamePlay(1050, 900)
+    g.move(g.actions()[0])
+    before = (g._rec.copy(), g._hist.copy(), list(g.actions()), g.state_key, g.state.turn)
+    bad = next(a for a in range(1584) if a not in g.actions())
+    for _ in range(2):                                      # twice: the refused-move counter of the handle must not stick
+        with pytest.raises(HiveError) as ei:
+            g.move(bad)
+        assert ei.value.code == -3
+        assert np.array_equal(g._rec, before[0]) and np.array_equal(g._hist, before[1])
+        assert g.actions() == before[2] and g.state_key == before[3] and g.state.turn == before[4]
+    g.move(g.actions()[-1])
+    assert g.state.turn == before[4] + 1 and not g.game_is_over()
+
+
+def test_search_survives_an_exhausted_node_pool_and_uct_with_slots():
+    """A node pool far too small for the simulations asked (the search treats a descent that cannot allocate as a
+    collision and gives its visit back): no crash, every simulation accounted for, legal moves.  And the UCT mode with four
+    leaves in flight (virtual loss 1): visits accounted for, support inside the legal set."""
+    from hive_alphazero_amd import batch, mcts, playout
+    G = 64
+    boards = playout.random_positions(G, seed=12)
+    B = batch.BoardBatch(G)
+    B.import_state(boards)
+    rb, rh = B.export_state()
+    over, _ = B.terminal()
+    mask, count, _ = B.legal()
+    live = (over == 0) & (rb[:, 33] < 55)
+
+    def flat_eval(planes):
+        n = planes.shape[0]
+        return torch.full((n, 1584), 1.0 / 1584, device="cuda"), torch.zeros((n,), device="cuda")
+
+    ts = mcts.TreeSearch(G, 40, flat_eval, plane_dtype=torch.float32, seed=1, max_nodes=10)
+    action, policy, sum_n = ts.search(rb, rh)
+    torch.cuda.synchronize()
+    hist = ts.leaf_histogram()
+    assert bool((hist.sum(1)[live] == 40).all().item()) and int(ts.node_counts().max().item()) <= 10
+    assert int(hist[:, 4].sum().item()) > 0                 # the pool really ran out
+    ok, legal = _support_inside_legal(policy, mask)
+    assert ok
+    has = live & (count > 0)
+    assert bool((legal[has].gather(1, action[has].long().view(-1, 1)) == 1).all().item())
+    ts.close()
+    tu = mcts.TreeSearch(G, 41, flat_eval, plane_dtype=torch.float32, slots=4, mode=mcts.UCT)
+    action, policy, sum_n = tu.search(rb, rh)
+    torch.cuda.synchronize()
+    hist = tu.leaf_histogram()
+    assert bool((sum_n[live] == 40 - hist[live][:, 4]).all().item())
+    ok, _ = _support_inside_legal(policy, mask)
+    assert ok
+    visits, total_value, priors = tu.root_stats()
+    assert bool((visits.sum(1)[live] == sum_n[live].float()).all().item())
+    tu.close(); B.close()
