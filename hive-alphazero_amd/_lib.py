@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "hive_batch_size", "hive_batch_set_stream", "hive_batch_reset", "hive_batch_step",
     "hive_batch_illegal_count", "hive_batch_legal", "hive_batch_encode", "hive_batch_terminal",
     "hive_batch_export", "hive_batch_import", "hive_movegen_launch", "hive_encode_launch",
-    "hive_terminal_launch", "hive_step_launch", "hive_leaf_launch",
+    "hive_terminal_launch", "hive_step_launch", "hive_leaf_launch", "hive_expand_launch",
     "hive_single_create", "hive_single_destroy", "hive_single_advance", "hive_single_encode",
     # include/hive_search.h
     "hive_search_create", "hive_search_destroy", "hive_search_set_stream", "hive_search_set_params",
@@ -90,6 +90,7 @@ def load():
     L.hive_movegen_launch.argtypes = [vp, i32, vp, vp, vp, vp]
     L.hive_encode_launch.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.hive_debug_tables.argtypes = [vp, vp, vp]
+    L.hive_expand_launch.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp]
     L.hive_terminal_launch.argtypes = [vp, i32, vp, vp, vp]
     L.hive_step_launch.argtypes = [vp, vp, i32, vp, vp, vp]
     L.hive_leaf_launch.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp]

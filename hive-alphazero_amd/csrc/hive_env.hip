@@ -890,6 +890,25 @@ int hive_encode_launch(const HiveBoard *boards, const HiveHistory *hist, int n, 
                          (hipStream_t)stream);
 }
 
+int hive_expand_launch(const HiveBoard *boards, const HiveHistory *hist, const void *features, int n, void *planes,
+                       HiveDType dtype, HiveLayout layout, void *stream)
+{
+    if (n <= 0 || boards == nullptr || features == nullptr || planes == nullptr)
+        return fail(HIVE_E_ARG, "expand: n <= 0 or a NULL buffer");
+    const int dt = (int)dtype, ly = (int)layout;
+    if (dt < 0 || dt > 2 || ly < 0 || ly > 1) return fail(HIVE_E_ARG, "expand: unknown dtype/layout");
+    const long long items = (long long)n * (kCells * HIVE_PLANES / 8);
+    dim3 grid((unsigned)((items + 255) / 256));
+    const unsigned long long *feat = (const unsigned long long *)features;
+#define HIVE_EXP_CASE(DT, LY)                                                                                  \
+    if (dt == DT && ly == LY)                                                                                  \
+        hipLaunchKernelGGL((hive_expand_kernel<DT, LY>), grid, dim3(256), 0, (hipStream_t)stream, boards, hist, feat, n, planes);
+    HIVE_EXP_CASE(0, 0) HIVE_EXP_CASE(0, 1) HIVE_EXP_CASE(1, 0) HIVE_EXP_CASE(1, 1) HIVE_EXP_CASE(2, 0) HIVE_EXP_CASE(2, 1)
+#undef HIVE_EXP_CASE
+    HIP_TRY(hipGetLastError());
+    return HIVE_OK;
+}
+
 int hive_terminal_launch(const HiveBoard *boards, int n, int8_t *over, int8_t *winner, void *stream)
 {
     if (n <= 0 || boards == nullptr) return fail(HIVE_E_ARG, "terminal: n <= 0 or boards == NULL");

@@ -157,3 +157,41 @@ def dataset_from_games(games):
             policies.append(np.asarray(policy, dtype=np.float32))
             values.append(value)
     return np.stack(states), np.stack(policies), np.asarray(values, dtype=np.float32)
+
+
+def dataset_tensors_gpu(games, device=None, dtype=None, layout="chw"):
+    """dataset_from_games on the GPU: the packed features, history bitboards and turn bytes of every row are uploaded
+    (1.5 KB per row) and widened to planes by the env's own plane writer (hive_expand_launch) -- what a trainer that
+    keeps up with the self-play GPUs uses.  -> (states [N,56,12,12] ("chw", what ChessNet takes) or [N,12,12,56],
+    policies float32 [N,1584], values float32 [N]) on `device`, values discounted like woker/optimize.py:42-65."""
+    import ctypes
+    import torch
+    from . import _lib
+    L = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    dtype = dtype or torch.float32
+    rows = [(g[0], p, sum(1 for q in g[1] if q[5] == p[5]), sum(1 for q in g[1][:k + 1] if q[5] == p[5]))
+            for g in games for k, p in enumerate(g[1])]
+    n = len(rows)
+    boards = np.zeros((n, 64), dtype=np.uint8)
+    hist = np.zeros((n, 2, 4, 2, 6), dtype=np.uint32)
+    feat = np.zeros((n, 144), dtype=np.uint64)
+    policies = np.zeros((n, 1584), dtype=np.float32)
+    values = np.zeros(n, dtype=np.float32)
+    for i, (vw, (words, hw, hlen, turn, policy, mover), total, seen) in enumerate(rows):
+        feat[i] = np.asarray(words, dtype=np.uint64).reshape(144)
+        hist[i, mover] = np.asarray(hw, dtype=np.uint32).reshape(4, 2, 6)
+        boards[i, 33] = turn
+        boards[i, 35] = (int(hlen) & 15) if mover == 0 else (int(hlen) << 4)
+        policies[i] = policy
+        value = -1.0 if vw == 0 else float(vw if mover == 0 else -vw)
+        values[i] = value if seen == total else value * DISCOUNTED_REWARD ** (total - seen)
+    shape = (n, 56, 12, 12) if layout == "chw" else (n, 12, 12, 56)
+    planes = torch.empty(shape, dtype=dtype, device=dev)
+    tb, th = torch.from_numpy(boards).to(dev), torch.from_numpy(hist.view(np.uint8).reshape(n, 384)).to(dev)
+    tf = torch.from_numpy(feat.view(np.int64)).to(dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    dt = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}[dtype]
+    _lib.check(L.hive_expand_launch(p(tb), p(th), p(tf), n, p(planes), dt, _lib.CHW if layout == "chw" else _lib.HWC,
+                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return planes, torch.from_numpy(policies).to(dev), torch.from_numpy(values).to(dev)

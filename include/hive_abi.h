@@ -141,6 +141,13 @@ int hive_movegen_launch(const HiveBoard *boards, int n, uint32_t *mask, int32_t 
 int hive_encode_launch(const HiveBoard *boards, const HiveHistory *hist, int n, void *planes,
                        HiveDType dtype, HiveLayout layout, void *workspace, void *stream);
 
+/* The second half of hive_encode_launch on its own: packed features (uint64[n][144], bit p of cell c = plane p, as the
+ * workspace of hive_encode_launch / the self-play records hold them) + history + the records' turn / history-length bytes
+ * -> the plane tensor.  Turns stored self-play records back into GamePlay.encode_board planes (env_hive.py:306-447) on the
+ * GPU; of `boards` only bytes 33 (turn) and 35 (history lengths) are read. */
+int hive_expand_launch(const HiveBoard *boards, const HiveHistory *hist, const void *features, int n, void *planes,
+                       HiveDType dtype, HiveLayout layout, void *stream);
+
 /* GamePlay.game_is_over over caller-owned records. */
 int hive_terminal_launch(const HiveBoard *boards, int n, int8_t *over, int8_t *winner, void *stream);
 /* GamePlay.move over caller-owned records: actions as hive_batch_step; legal_mask (uint32[n][HIVE_MASK_WORDS]) may be

@@ -496,3 +496,29 @@ def test_search_survives_an_exhausted_node_pool_and_uct_with_slots():
     visits, total_value, priors = tu.root_stats()
     assert bool((visits.sum(1)[live] == sum_n[live].float()).all().item())
     tu.close(); B.close()
+
+
+def test_compact_games_widen_to_trainer_tensors_on_the_gpu():
+    """records.dataset_tensors_gpu (hive_expand_launch on stored packed features) == records.dataset_from_games (host): planes in
+    both layouts and three dtypes, policies, discounted values -- on games the GPU engine really played."""
+    from hive_alphazero_amd import mcts, records
+
+    def flat_eval(planes):
+        n = planes.shape[0]
+        return torch.full((n, 1584), 1.0 / 1584, device="cuda"), torch.zeros((n,), device="cuda")
+
+    sp = mcts.SelfPlay(8, 3, flat_eval, seed=4, plane_dtype=torch.float32, game_ids=range(8))
+    games = []
+    while sp.running():
+        sp.play_ply()
+        games += sp.drain_finished()
+    sp.close()
+    assert len(games) == 8
+    states, policies, values = records.dataset_from_games(games)
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
+        chw, pol, val = records.dataset_tensors_gpu(games, dtype=dtype, layout="chw")
+        hwc, _, _ = records.dataset_tensors_gpu(games, dtype=dtype, layout="hwc")
+        torch.cuda.synchronize()
+        assert np.array_equal(hwc.float().cpu().numpy(), states)
+        assert np.array_equal(chw.float().cpu().numpy(), states.transpose(0, 3, 1, 2))
+        assert np.array_equal(pol.cpu().numpy(), policies) and np.allclose(val.cpu().numpy(), values, atol=1e-6)
