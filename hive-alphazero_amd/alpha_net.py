@@ -566,8 +566,8 @@ class InferenceNet:
             g = (graph, static_in, out)
             self._graphs[B] = g
             if self._tunable_before is not None:
-                # TunableOp is process-global: left on, every later GEMM of the process (a training step in the same
-                # process ran 25.9 instead of 16.6 ms) goes through it; the captured graph does not need it any more
+                # TunableOp's switch is process-global: hand it back as it was, so that whatever else runs in this process
+                # (a Trainer, another library) keeps its own GEMM selection; the captured graph holds the picked kernels
                 import torch.cuda.tunable as tn
                 tn.enable(self._tunable_before)
                 self._tunable_before = None
