@@ -149,6 +149,37 @@ def selfplay_measure(args, rank, local_rank, world):
         out["whole_games"] = whole
         out["games_per_min"] = whole["games_per_min"]
 
+    if args.whole_games and args.records:
+        # the same whole games with the per-ply records ON (woker/self_play.py:159-160: a row per ply; :178-193 values at the
+        # end): features + policy + mover copied to the host every ply, finished games cut out and handed over
+        # (drain_finished) -- what a producer does; the engine is otherwise identical (same seed, same game ids)
+        lo = rank * args.games
+        sp = mcts.SelfPlay(args.games, args.sims, net, device=local_rank, slots=args.slots, seed=1234, keep_records=True,
+                           game_ids=range(lo, lo + args.games), max_finished_kept=2 * args.games)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        plies, games_out, rows_out = 0, 0, 0
+        while True:
+            sp.play_ply()
+            plies += 1
+            for entry in sp.drain_finished():
+                games_out += 1
+                rows_out += len(entry[1])
+            if sp.running() == 0 or plies > 60:
+                break
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        rec = {"games": sp.finished, "games_with_records": games_out, "rows": rows_out, "wall_s": round(el, 3),
+               "plies_played": plies, "games_per_min": round(sp.finished / el * 60.0, 2),
+               "ms_per_ply": round(el / plies * 1e3, 2), "illegal_moves": sp.env.illegal_count(),
+               "dropped_games": sp.dropped_games, "unrecorded_games": sp.unrecorded_games}
+        if "whole_games" in out:
+            rec["vs_engine_only"] = round(rec["games_per_min"] / out["whole_games"]["games_per_min"], 4)
+        sp.close()
+        out["whole_games_records_on"] = rec
+        out["games_per_min_engine_only"] = out.get("games_per_min")
+        out["games_per_min"] = rec["games_per_min"]          # the producer number is the M1 figure
+
     if args.selfplay_plies > 0:
         sp = mcts.SelfPlay(args.games, args.sims, net, device=local_rank, slots=args.slots, seed=1234, keep_records=False,
                            game_ids=hd.game_id_stream(rank, world))
@@ -179,9 +210,46 @@ def selfplay_measure(args, rank, local_rank, world):
         out["steady_state"] = steady
         out.setdefault("games_per_min", steady["games_per_min_counted"])
         out["leaf_evals_per_s"] = round(executed / el, 1)
+    del net
+    if args.worker and world == 1 and args.whole_games:
+        out["producer_selfplay_worker"] = selfplay_worker_measure(args, local_rank)
     if args.cpu_baseline_selfplay and world == 1:            # host baselines are an N = 1 measurement
         out["cpu_baseline"] = selfplay_cpu_baseline(args.sims)
+        out["cpu_baseline"]["all_cores"] = selfplay_cpu_baseline_all_cores(args.sims)
     return out
+
+
+def selfplay_worker_measure(args, local_rank):
+    """M1 as the PRODUCER the reference's woker/self_play.py is (:37-75 pool, :100-112 files): SelfPlayWorker spawns one
+    child for this GPU, the child builds the network and the engine, plays `games` whole games with records on and sends
+    every finished game through the queue; the parent writes compact play_<ts>.npz files.  Timed from the spawn to the
+    last flushed file (`wall_s_total`: includes the child's interpreter start, `import torch`, network build, HIP-graph
+    capture and GEMM tuning -- a one-off per run) and from the child's "ready" message (`wall_s_playing`)."""
+    import shutil
+    import tempfile
+    from hive_alphazero_amd.self_play import SelfPlayWorker
+    d = tempfile.mkdtemp(prefix="hive_bench_selfplay_")
+    try:
+        w = SelfPlayWorker(total_games=args.games, games_per_gpu=args.games, sims=args.sims, gpus=[local_rank], seed=1234,
+                           slots=args.slots, datapath=d, games_per_file=256, report_every=0, row_format="compact",
+                           log=lambda *_: None, warmup=True)
+        t0 = time.time()
+        res = w.start(timeout_s=900)
+        t1 = time.time()
+        ready = w.ready_at.get(0, t0)
+        files = [os.path.getsize(f) for f in w.files]
+        rows = sum(len(e[1]) for e in res.values())
+        return {"games": len(res), "rows": rows, "files": len(files), "file_bytes": int(sum(files)),
+                "wall_s_total": round(t1 - t0, 3), "child_startup_s": round(ready - t0, 3),
+                "wall_s_playing": round(t1 - ready, 3),
+                "games_per_min_playing": round(len(res) / max(t1 - ready, 1e-9) * 60.0, 2),
+                "games_per_min_total": round(len(res) / (t1 - t0) * 60.0, 2),
+                "row_format": "compact (.npz of packed features + sparse policies; records.rows_from_game expands to the "
+                              "reference's JSON rows)",
+                "note": "child_startup_s = interpreter + import torch + network + engine + one warm-up ply (graph capture, "
+                        "GEMM tuning): paid once per run, not per 1024 games"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def training_measure(steps, batch=512):
@@ -240,6 +308,108 @@ def selfplay_cpu_baseline(sims, budget_s=10.0):
                       "per 54-ply game"}
 
 
+def _cpu_selfplay_proc(a):
+    """One host core's worth of the reference's process model (one game per process, woker/self_play.py:54-56)."""
+    sims, budget_s, seed = a
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hive_alphazero_amd.solo_play as sp
+    from mcts_stub import StubPipe
+    from oracle_env import OracleGamePlay
+    sp.SEARCH_THREADS = 1
+    np.random.seed(seed)
+    player = sp.HivePlayer(pipes=[StubPipe()])
+    player.simulation_num_per_move = sims
+    t0 = time.perf_counter()
+    plies = 0
+    while time.perf_counter() - t0 < budget_s:
+        g = OracleGamePlay()
+        while not (g.game_is_over() or g.state.turn >= 55) and time.perf_counter() - t0 < budget_s:
+            a_, _ = player.action(g)
+            g.move(a_)
+            plies += 1
+    return plies, time.perf_counter() - t0
+
+
+def selfplay_cpu_baseline_all_cores(sims, budget_s=10.0):
+    """The one-core baseline above on every host core the box grants: one self-play process per core (spawned: this
+    process has a live HIP context), each playing whole games for `budget_s` seconds; stub evaluator, network cost excluded."""
+    import multiprocessing as mp
+    cores = host_cores()
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.map(_cpu_selfplay_proc, [(sims, budget_s, 100 + i) for i in range(cores)])
+    plies = sum(r[0] for r in res)
+    el = max(r[1] for r in res)
+    return {"value": round(plies / 54.0 / el * 60.0, 3), "unit": "games/min", "cores": cores, "kind": "port",
+            "sample": f"{plies} searched plies in {el:.1f} s over {cores} processes (one game per process, the reference's "
+                      f"model), {sims} sims, stub evaluator (network cost excluded), per 54-ply game"}
+
+
+ENCODE_BYTES_PER_BOARD = 16128       # 56 x 144 x 2 B planes written per board (SURVEY.md 8d), bf16
+
+
+def encode_measure(L, n=65536, steps=20):
+    """The one HBM-bound kernel of the path: hive_expand_kernel, the planes writer (GamePlay.encode_board's output,
+    env_hive.py:320-447): packed features (1,152 B / board) + history (384 B) + record (64 B) in, 16,128 B of bf16 planes
+    out per board.  Also the whole encode (hive_piece_kernel<true> + the writer)."""
+    import torch
+    from hive_alphazero_amd import playout
+    from hive_alphazero_amd._lib import BF16, HWC
+    boards = playout.random_positions(4096, seed=4242).repeat(n // 4096, 1).contiguous()
+    hist = torch.zeros((n, 384), dtype=torch.uint8, device="cuda")
+    ws = torch.empty((n * 144,), dtype=torch.int64, device="cuda")
+    planes = torch.empty((n, 12, 12, 56), dtype=torch.bfloat16, device="cuda")
+    st = torch.cuda.current_stream()
+    sp = ctypes.c_void_p(st.cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    def full():
+        rc = L.hive_encode_launch(P(boards), P(hist), n, P(planes), BF16, HWC, P(ws), sp)
+        if rc != 0:
+            raise RuntimeError(L.hive_last_error().decode())
+    def writer():
+        rc = L.hive_expand_launch(P(boards), P(hist), P(ws), n, P(planes), BF16, HWC, sp)
+        if rc != 0:
+            raise RuntimeError(L.hive_last_error().decode())
+    out = {"workload": f"encode_{n}", "boards_per_launch": n}
+    for name, fn in (("encode (features + planes writer)", full), ("planes writer (hive_expand_kernel)", writer)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(steps):
+            fn()
+        e1.record(st)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        key = "encode" if name.startswith("encode") else "planes_writer"
+        out[key] = {"kernel": name, "ms_per_launch": round(ms, 4), "Mboards_per_s": round(n / ms / 1e3, 2)}
+        if key == "planes_writer":
+            alg = n * (ENCODE_BYTES_PER_BOARD + 1152 + 384 + 64)
+            out[key]["roofline"] = {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                                    "algorithmic_bytes_per_launch": alg,
+                                    "note": "16,128 B written + 1,600 B read per board; PMC FETCH/WRITE_SIZE passes: "
+                                            "profiles/r03_encode_pmc.md"}
+    return out
+
+
+def relaunch_under_torchrun(argv, gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks under torch.distributed.run as a CHILD process (this
+    process has not touched the GPU yet and never will), relay rank 0's JSON line, exit with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,7 +431,18 @@ def main():
                     "concurrent launches stretch the per-kernel durations rocprof reports)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
                     "the multi-rank path on a single GPU")
+    ap.add_argument("--no-records", dest="records", action="store_false", help="skip the records-on whole-game self-play leg")
+    ap.add_argument("--no-worker", dest="worker", action="store_false", help="skip the SelfPlayWorker (spawned producer) leg")
+    ap.add_argument("--encode-boards", type=int, default=65536, help="boards per launch of the planes-writer side measurement (0 = skip)")
     args = ap.parse_args()
+
+    # ---- N ranks: either the driver started us under torch.distributed.run (RANK / WORLD_SIZE set), or we do it ourselves
+    if "RANK" not in os.environ:
+        if args.gpus > 1:
+            raise SystemExit(relaunch_under_torchrun(sys.argv[1:], args.gpus))
+    elif int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: start one rank per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)")
 
     t_start = time.perf_counter()
     import numpy as np
@@ -326,8 +507,8 @@ def main():
     mean_legal = float(count.float().mean().item())
 
     t_side0 = time.perf_counter()
-    # side measurement: legal set AND its compaction into sorted action ids (hive_list_kernel = GamePlay.encode_action,
-    # env_hive.py:287-304) -- what GamePlay.actions() returns
+    # side measurement: legal set AND its compaction into sorted action ids (GamePlay.encode_action, env_hive.py:287-304)
+    # -- what GamePlay.actions() returns -- by the fused launch
     with_list = None
     if rank == 0:
         lst = torch.empty((n, 256), dtype=torch.int16, device="cuda")
@@ -343,7 +524,8 @@ def main():
         torch.cuda.synchronize()
         lms = l0.elapsed_time(l1) / args.steps
         with_list = {"Mboards_per_s": round(n / lms / 1e3, 2), "ms_per_step": round(lms, 6),
-                     "note": "hive_piece_kernel + hive_list_kernel (mask -> ascending int16 ids), 2 launches per step"}
+                     "note": "ONE launch: hive_piece_kernel<false, true> keeps the destination boards in LDS and its waves build the "
+                             "ascending int16 id lists (GamePlay.actions()) behind one barrier"}
     # side measurement: the same 4096-board steps, independent batches issued round-robin on 4 HIP streams
     # (what a self-play engine with several game groups does); NOT the headline value
     overlapped = None
@@ -421,6 +603,13 @@ def main():
                 "note": "pinned host buffers, one stream, copies and kernel serialised; never the headline value"}
         assert torch.equal(hm, mask.cpu())
 
+    encode = None
+    if rank == 0 and args.encode_boards > 0:
+        try:
+            encode = encode_measure(L, args.encode_boards)
+        except Exception as exc:
+            encode = {"error": repr(exc)}
+
     selfplay = None
     if args.selfplay_plies > 0 or args.whole_games:
         try:
@@ -477,6 +666,7 @@ def main():
             "overlapped_4_streams": overlapped,
             "saturated": sat,
             "host_buffers_pcie_inclusive": pcie,
+            "encode": encode,
             "selfplay": selfplay,
             "training": training,
         }

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "hive_batch_size", "hive_batch_set_stream", "hive_batch_reset", "hive_batch_step",
     "hive_batch_illegal_count", "hive_batch_legal", "hive_batch_encode", "hive_batch_terminal",
     "hive_batch_export", "hive_batch_import", "hive_movegen_launch", "hive_encode_launch",
-    "hive_terminal_launch", "hive_step_launch", "hive_leaf_launch", "hive_expand_launch",
+    "hive_terminal_launch", "hive_step_launch", "hive_step_launch_counted", "hive_leaf_launch", "hive_expand_launch",
     "hive_single_create", "hive_single_destroy", "hive_single_advance", "hive_single_encode",
     # include/hive_search.h
     "hive_search_create", "hive_search_destroy", "hive_search_set_stream", "hive_search_set_params",
@@ -38,7 +38,8 @@ ABI_SYMBOLS = [
     "hive_search_node_counts", "hive_search_set_transpositions", "hive_search_transposition_hits",
     "hive_search_set_game_ids", "hive_search_root_stats", "hive_search_leaf_histogram", "hive_search_sample_noise",
     # include/hive_nn.h
-    "hive_nn_conv3x3", "hive_nn_resblock", "hive_nn_bn_workspace_floats", "hive_nn_bn_act_fwd", "hive_nn_bn_act_bwd",
+    "hive_nn_conv3x3", "hive_nn_resblock", "hive_nn_conv3x3_dt", "hive_nn_resblock_dt", "hive_nn_tower",
+    "hive_nn_bn_workspace_floats", "hive_nn_bn_act_fwd", "hive_nn_bn_act_bwd",
     "hive_nn_pack_conv3x3_weights", "hive_nn_conv3x3_wgrad", "hive_nn_wgrad_workspace_floats",
 ]
 
@@ -93,6 +94,7 @@ def load():
     L.hive_expand_launch.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp]
     L.hive_terminal_launch.argtypes = [vp, i32, vp, vp, vp]
     L.hive_step_launch.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.hive_step_launch_counted.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     L.hive_leaf_launch.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.hive_single_create.argtypes = [i32, ctypes.POINTER(vp)]
     L.hive_single_destroy.argtypes = [vp]
@@ -116,6 +118,9 @@ def load():
                                            vp, vp]
     L.hive_nn_conv3x3.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp]
     L.hive_nn_resblock.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
+    L.hive_nn_conv3x3_dt.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.hive_nn_resblock_dt.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.hive_nn_tower.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     f32, i64 = ctypes.c_float, ctypes.c_longlong
     L.hive_nn_bn_workspace_floats.restype = i32
     L.hive_nn_bn_act_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i64, i32, i32, vp]

@@ -367,8 +367,8 @@ def _fold(conv, bn):
     return w * scale.view(-1, 1, 1, 1), bn.bias.detach().float() + (b - bn.running_mean.detach().float()) * scale
 
 
-def _frag_major(w, dev):
-    """[256, cin, 3, 3] fp32 -> bf16 [9][cinp/32][16][64][8]: the MFMA-fragment-major weight layout of
+def _frag_major(w, dev, dtype=torch.bfloat16):
+    """[256, cin, 3, 3] fp32 -> bf16 / fp16 [9][cinp/32][16][64][8]: the MFMA-fragment-major weight layout of
     hive_nn_conv3x3 (include/hive_nn.h).  tap = dy*3+dx; cin zero-padded to a multiple of 64; inside a
     (tap, 32-channel k-step, 16-output-channel tile) block, lane = (c%32)//8*16 + k%16 holds 8 consecutive c."""
     k, cin = w.shape[0], w.shape[1]
@@ -378,23 +378,27 @@ def _frag_major(w, dev):
         t = torch.cat([t, torch.zeros(9, k, cinp - cin, dtype=t.dtype, device=t.device)], dim=2)
     t = t.reshape(9, 16, 16, cinp // 32, 4, 8)          # tap, m-tile, row, k-step, k-group, 8
     t = t.permute(0, 3, 1, 4, 2, 5)                     # tap, k-step, m-tile, k-group, row, 8
-    return t.to(dev, torch.bfloat16).contiguous()
+    return t.to(dev, dtype).contiguous()
 
 
 class InferenceNet:
     """Batched leaf evaluator for a ChessNet (eval mode).  __call__(planes_hwc) -> (p fp32 [B,1584], v fp32 [B]).
 
-    conv = "hip" (default for bf16 on a GPU): the 39 3x3 convolutions run in the hand-written MFMA
-    kernel hive_nn_conv3x3 with bias / skip / ReLU fused; conv = "torch": MIOpen through F.conv2d."""
+    conv = "hip" (default for bf16 / fp16 on a GPU): the 39 3x3 convolutions run in the hand-written MFMA kernels
+    (hive_nn_conv3x3_dt for the stem, hive_nn_resblock_dt per residual block) with bias / skip / ReLU fused;
+    conv = "torch": MIOpen through F.conv2d (the fp32 path, the reference's own precision, api_hive.py:62-69).
+    tower: 0 = one hive_nn_resblock_dt launch per residual block (default: measured fastest, profiles/r03_net_tower.md);
+    1 / 2 / 3 = the whole tower in one hive_nn_tower launch (its boards_per_group modes; same bits)."""
 
-    def __init__(self, net, dtype=torch.bfloat16, device=None, use_graph=True, conv=None, tune_gemms=True):
+    def __init__(self, net, dtype=torch.bfloat16, device=None, use_graph=True, conv=None, tune_gemms=True, tower=0):
         dev = torch.device(device) if device is not None else next(net.parameters()).device
         self.device, self.dtype, self.use_graph = dev, dtype, use_graph and dev.type == "cuda"
+        hip_ok = dev.type == "cuda" and dtype in (torch.bfloat16, torch.float16)
         if conv is None:
-            conv = "hip" if (dev.type == "cuda" and dtype == torch.bfloat16) else "torch"
-        if conv == "hip" and not (dev.type == "cuda" and dtype == torch.bfloat16):
-            raise ValueError("the HIP convolution path is bf16 on a GPU")
-        self.conv = conv
+            conv = "hip" if hip_ok else "torch"
+        if conv == "hip" and not hip_ok:
+            raise ValueError("the HIP convolution path is bf16 or fp16 on a GPU")
+        self.conv, self.tower = conv, int(tower)
         # large leaf batches: let PyTorch's TunableOp pick the hipBLASLt solutions of the head GEMMs once, before the graph
         # is captured (the default heuristic runs the 1024 x 18432 x 1584 policy FC at 178 us, the tuned pick at 92 us)
         self.tune_gemms = tune_gemms and dev.type == "cuda"
@@ -416,14 +420,20 @@ class InferenceNet:
         out = {}
         if conv == "hip":
             w, b = _fold(net.conv.conv1, net.conv.bn1)
-            out["h_stem"] = (_frag_major(w, dev), b.to(dev, torch.float32).contiguous())
+            out["h_stem"] = (_frag_major(w, dev, dtype), b.to(dev, torch.float32).contiguous())
+            # the 38 tower convolutions back to back in ONE buffer ([38][9][8][16][64][8] + [38][256] biases: what
+            # hive_nn_tower reads); the per-block tuples below are views into it
+            tw = torch.empty((38, 9 * 8 * 16 * 64 * 8), dtype=dtype, device=dev)
+            tb = torch.empty((38, 256), dtype=torch.float32, device=dev)
             h_blocks = []
             for i in range(19):
                 rb = getattr(net, "res_%i" % i)
-                w1, b1 = _fold(rb.conv1, rb.bn1)
-                w2, b2 = _fold(rb.conv2, rb.bn2)
-                h_blocks.append((_frag_major(w1, dev), b1.to(dev, torch.float32).contiguous(),
-                                 _frag_major(w2, dev), b2.to(dev, torch.float32).contiguous()))
+                for j, (cv, bn) in enumerate(((rb.conv1, rb.bn1), (rb.conv2, rb.bn2))):
+                    wj, bj = _fold(cv, bn)
+                    tw[2 * i + j].copy_(_frag_major(wj, dev, dtype).reshape(-1))
+                    tb[2 * i + j].copy_(bj)
+                h_blocks.append((tw[2 * i], tb[2 * i], tw[2 * i + 1], tb[2 * i + 1]))
+            out["h_tower"] = (tw, tb)
             out["h_blocks"] = h_blocks
 
         def prep(w, b):
@@ -465,29 +475,37 @@ class InferenceNet:
 
     def _conv_hip(self, x, cin, w, b, res, out):
         import ctypes
-        from ._lib import check
+        from ._lib import BF16, F16, check
         st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        check(self._L.hive_nn_conv3x3(ctypes.c_void_p(x.data_ptr()), cin, ctypes.c_void_p(w.data_ptr()),
-                                      ctypes.c_void_p(b.data_ptr()),
-                                      ctypes.c_void_p(res.data_ptr()) if res is not None else None,
-                                      ctypes.c_void_p(out.data_ptr()), x.shape[0], 1, st))
+        check(self._L.hive_nn_conv3x3_dt(ctypes.c_void_p(x.data_ptr()), cin, ctypes.c_void_p(w.data_ptr()),
+                                         ctypes.c_void_p(b.data_ptr()),
+                                         ctypes.c_void_p(res.data_ptr()) if res is not None else None,
+                                         ctypes.c_void_p(out.data_ptr()), x.shape[0], 1,
+                                         BF16 if self.dtype == torch.bfloat16 else F16, st))
         return out
 
     def _tower_hip(self, x_hwc):
         B = x_hwc.shape[0]
         x_hwc = x_hwc.contiguous()
-        bufs = [torch.empty((B, 12, 12, 256), dtype=torch.bfloat16, device=self.device) for _ in range(3)]
+        bufs = [torch.empty((B, 12, 12, 256), dtype=self.dtype, device=self.device) for _ in range(3)]
         s = self._conv_hip(x_hwc, 56, self.h_stem[0], self.h_stem[1], None, bufs[0])
         cur = 0
         import ctypes
-        from ._lib import check
+        from ._lib import BF16, F16, check
+        dt = BF16 if self.dtype == torch.bfloat16 else F16
         st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if self.tower:
+            tw, tb = self.h_tower
+            check(self._L.hive_nn_tower(ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(tw.data_ptr()),
+                                        ctypes.c_void_p(tb.data_ptr()), ctypes.c_void_p(bufs[1].data_ptr()), B, 19, dt,
+                                        self.tower, st))
+            return bufs[1].permute(0, 3, 1, 2)
         for w1, b1, w2, b2 in self.h_blocks:
             if self.fuse_blocks:
                 s2 = bufs[(cur + 1) % 3]                                     # whole residual block in one launch
-                check(self._L.hive_nn_resblock(ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(w1.data_ptr()),
-                                               ctypes.c_void_p(b1.data_ptr()), ctypes.c_void_p(w2.data_ptr()),
-                                               ctypes.c_void_p(b2.data_ptr()), ctypes.c_void_p(s2.data_ptr()), B, st))
+                check(self._L.hive_nn_resblock_dt(ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(w1.data_ptr()),
+                                                  ctypes.c_void_p(b1.data_ptr()), ctypes.c_void_p(w2.data_ptr()),
+                                                  ctypes.c_void_p(b2.data_ptr()), ctypes.c_void_p(s2.data_ptr()), B, dt, st))
                 s, cur = s2, (cur + 1) % 3
             else:
                 o = self._conv_hip(s, 256, w1, b1, None, bufs[(cur + 1) % 3])
@@ -552,25 +570,28 @@ class InferenceNet:
         if g is None:
             static_in = torch.zeros_like(planes_hwc)
             static_in.copy_(planes_hwc)
-            s = torch.cuda.Stream(self.device)
-            s.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(s):
-                if self.tune_gemms and B >= 256:
-                    self._tune(static_in)
-                for _ in range(2):
-                    self._forward(static_in)
-            torch.cuda.current_stream(self.device).wait_stream(s)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                out = self._forward(static_in)
-            g = (graph, static_in, out)
-            self._graphs[B] = g
-            if self._tunable_before is not None:
-                # TunableOp's switch is process-global: hand it back as it was, so that whatever else runs in this process
-                # (a Trainer, another library) keeps its own GEMM selection; the captured graph holds the picked kernels
-                import torch.cuda.tunable as tn
-                tn.enable(self._tunable_before)
-                self._tunable_before = None
+            try:
+                s = torch.cuda.Stream(self.device)
+                s.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(s):
+                    if self.tune_gemms and B >= 256:
+                        self._tune(static_in)
+                    for _ in range(2):
+                        self._forward(static_in)
+                torch.cuda.current_stream(self.device).wait_stream(s)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    out = self._forward(static_in)
+                g = (graph, static_in, out)
+                self._graphs[B] = g
+            finally:
+                if self._tunable_before is not None:
+                    # TunableOp's switch is process-global: hand it back as it was -- also when tuning or the capture
+                    # failed --, so that whatever else runs in this process (a Trainer, another library) keeps its own
+                    # GEMM selection; the captured graph holds the picked kernels
+                    import torch.cuda.tunable as tn
+                    tn.enable(self._tunable_before)
+                    self._tunable_before = None
         graph, static_in, out = g
         static_in.copy_(planes_hwc)
         graph.replay()

@@ -19,6 +19,7 @@
 //   pieces.py:35-158      per-piece move_is_valid
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <new>
 #include <type_traits>
@@ -400,17 +401,76 @@ __device__ __forceinline__ void pin_phase(Smem<FULL> &sm, int wave, int lane)
 // cell test on a lane-distributed board (result replicated over the quad)
 __device__ __forceinline__ bool bb_test(BB x, unsigned cell) { return bb_any(bb_and(x, bb_bit(cell))); }
 
+// GamePlay.encode_action (env_hive.py:287-304) for one board, by one wave: {slot: destination board} (66 words in LDS)
+// -> ascending action ids.  Action id = cell * 11 + slot, i.e. the bit index of the 11 x 144 slot-major bit matrix
+// TRANSPOSED: (1) lane l of pass t (three passes cover the 144 cells) gathers the 11 slot bits of cell 64 t + l and ORs
+// them at bit cell * 11 of a 1584-bit id-ordered mask in LDS; (2) lane j then owns word j of that mask (50 words): a
+// ballot / v_mbcnt prefix over the words' popcounts gives each word its place in the list, its set bits are laid down
+// in an LDS row, and the row leaves as one coalesced 8-byte store per lane (-1 padded).
+__device__ __forceinline__ void build_id_list(const uint32_t *dest, uint32_t *idmask, int16_t *rowbuf, int16_t *out, int lane)
+{
+    reinterpret_cast<unsigned long long *>(rowbuf)[lane] = 0xFFFFFFFFFFFFFFFFull;      // four -1 entries per lane
+    if (lane < 52) idmask[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // same-wave LDS traffic only: program order suffices
+    __builtin_amdgcn_wave_barrier();
+    HIVE_UNROLL for (int t = 0; t < 3; ++t) {
+        const unsigned cell = 64u * (unsigned)t + (unsigned)lane;
+        if (cell < (unsigned)kCells) {
+            unsigned wi, bit, bits = 0u;
+            cell_word_bit(cell, wi, bit);
+            HIVE_UNROLL for (unsigned sl = 0; sl < 11u; ++sl) bits |= ((dest[sl * 6u + wi] >> bit) & 1u) << sl;
+            if (bits) {
+                const unsigned off = cell * 11u, w = off >> 5, sh = off & 31u;
+                atomicOr(&idmask[w], bits << sh);
+                if (sh > 21u) atomicOr(&idmask[w + 1u], bits >> (32u - sh));
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t w = lane < 50 ? idmask[lane] : 0u;
+    const unsigned c = (unsigned)__popc(w);                     // <= 32: six bits
+    int pos = 0;
+    HIVE_UNROLL for (unsigned k = 0; k < 6u; ++k) {
+        const unsigned long long bal = __ballot((c >> k) & 1u);
+        pos += (int)(__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)) << k);
+    }
+    while (w) {                                                 // this word's ids in ascending order
+        const unsigned bidx = (unsigned)__builtin_ctz(w);
+        w &= w - 1u;
+        if (pos < HIVE_LIST_CAP) rowbuf[pos] = (int16_t)((unsigned)lane * 32u + bidx);
+        ++pos;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    reinterpret_cast<unsigned long long *>(out)[lane] = reinterpret_cast<const unsigned long long *>(rowbuf)[lane];
+    __builtin_amdgcn_wave_barrier();                            // (the buffers may be reused by this wave)
+}
+
+// LDS of the fused list variant: the workgroup's destination boards and one list row per wave
+template <bool LIST> struct ListMem { uint32_t pad; };
+template <> struct alignas(16) ListMem<true> {
+    uint32_t dest[16][HIVE_MASK_WORDS + 2];
+    uint32_t idmask[NW][52];
+    alignas(8) int16_t rowbuf[NW][HIVE_LIST_CAP];
+};
+
 // The piece kernel.  FULL = false: legal mask/count of the side to move (GamePlay.actions).
 // FULL = true: both colours; additionally the 56 feature bits per cell (planes 0-35, 44-55 of
 // GamePlay.make_state_value; history planes 36-43 and plane 31 are added by hive_expand_kernel).
 // There is no barrier after the piece work: each wave ORs its results into LDS and leaves; the
 // last wave to finish writes the workgroup's boards out.
-template <bool FULL>
+// LIST = true (movegen only): the sorted id list (GamePlay.actions() itself) leaves the same launch: the destination
+// boards are also kept in LDS, the waves meet at one barrier and build the lists of the workgroup's 16 boards between
+// them -- no second launch, no re-read of the mask.
+template <bool FULL, bool LIST = false>
 __global__ void __launch_bounds__(NW * 64, FULL ? 5 : HIVE_PIECE_WPE)
 hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restrict__ mask,
-                  int32_t *__restrict__ count, unsigned long long *__restrict__ feat)
+                  int32_t *__restrict__ count, unsigned long long *__restrict__ feat, int16_t *__restrict__ list)
 {
+    static_assert(!(FULL && LIST), "the fused list belongs to the movegen variant");
     __shared__ Smem<FULL> sm;
+    __shared__ ListMem<LIST> lm;
     constexpr int G = Smem<FULL>::G;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -516,6 +576,10 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         if (valid && mask != nullptr && (lane & 3) < 3)
             *reinterpret_cast<uint2 *>(mask + (gbase + bl) * HIVE_MASK_WORDS + wv * 6 + 2 * (lane & 3)) =
                 make_uint2(pc.D.lo, pc.D.hi);
+        if constexpr (LIST) {
+            if ((lane & 3) < 3)
+                *reinterpret_cast<uint2 *>(&lm.dest[bl][wv * 6 + 2 * (lane & 3)]) = make_uint2(pc.D.lo, pc.D.hi);
+        }
         const int nd = __popc(pc.D.lo) + __popc(pc.D.hi);       // destination sets of different pieces are disjoint
         if (nd) atomicAdd(&sm.nlegal[bl], nd);
     }
@@ -566,6 +630,17 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         }
     }
 
+    if constexpr (LIST) {
+        // ---------------- fused encode_action: every wave stays, the 16 boards' lists are shared out between the 11 waves
+        // (a raw barrier behind an LDS-only wait: __syncthreads() would also wait for the mask stores above to be
+        // acknowledged by memory -- a microsecond or two nobody needs; only the LDS image must be complete)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int nbl = (int)((n - gbase) < G ? (n - gbase) : G);
+        if (wave_id == 0 && count != nullptr && lane < nbl) count[gbase + lane] = sm.nlegal[lane];
+        for (int b = wave_id; b < nbl; b += NW)
+            build_id_list(lm.dest[b], lm.idmask[wave_id], lm.rowbuf[wave_id], list + (gbase + b) * HIVE_LIST_CAP, lane);
+        return;
+    }
     // ---------------- tail: the last wave to arrive writes the workgroup's results
     int prior = 0;
     if (lane == 0) prior = __hip_atomic_fetch_add(&sm.done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -583,15 +658,12 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     }
 }
 
-// GamePlay.encode_action (env_hive.py:287-304): {slot: destination board} -> ascending action ids.
-// One wave per board.  Action id = cell * 11 + slot, so ascending ids = cells in order, slots in order inside a cell:
-// lane l of pass t (three passes cover the 144 cells) gathers the 11 slot bits of cell 64 t + l from the destination
-// boards held in LDS, a wave prefix sum of the popcounts gives every cell its place in the list, the ids are laid down in
-// an LDS row and leave as one coalesced 8-byte store per lane (-1 padded).
+// GamePlay.encode_action over an existing mask (one wave per board; build_id_list above).
 __global__ void __launch_bounds__(256)
 hive_list_kernel(const uint32_t *__restrict__ mask, int n, int16_t *__restrict__ list)
 {
     __shared__ uint32_t dest[4][HIVE_MASK_WORDS + 2];
+    __shared__ uint32_t idmask[4][52];
     __shared__ __attribute__((aligned(8))) int16_t rowbuf[4][HIVE_LIST_CAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long b = (long long)blockIdx.x * 4 + wv;
@@ -599,36 +671,7 @@ hive_list_kernel(const uint32_t *__restrict__ mask, int n, int16_t *__restrict__
     const uint32_t *m = mask + b * HIVE_MASK_WORDS;
     dest[wv][lane] = m[lane];
     if (lane < HIVE_MASK_WORDS - 64) dest[wv][64 + lane] = m[64 + lane];
-    reinterpret_cast<unsigned long long *>(rowbuf[wv])[lane] = 0xFFFFFFFFFFFFFFFFull;      // four -1 entries per lane
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // same-wave LDS traffic only: program order suffices
-    __builtin_amdgcn_wave_barrier();
-    int total = 0;
-    for (int t = 0; t < 3; ++t) {
-        const unsigned cell = 64u * (unsigned)t + (unsigned)lane;
-        unsigned bits = 0u;
-        if (cell < (unsigned)kCells) {
-            unsigned wi, bit;
-            cell_word_bit(cell, wi, bit);
-            HIVE_UNROLL for (unsigned s = 0; s < 11u; ++s) bits |= ((dest[wv][s * 6u + wi] >> bit) & 1u) << s;
-        }
-        const int cnt = __popc(bits);
-        int incl = cnt;                                         // inclusive prefix sum over the wave
-        HIVE_UNROLL for (int o = 1; o < 64; o <<= 1) {
-            const int y = __shfl_up(incl, o);
-            if (lane >= o) incl += y;
-        }
-        int pos = total + incl - cnt;
-        while (bits) {                                          // this cell's legal slots in ascending order
-            const unsigned s = (unsigned)__builtin_ctz(bits);
-            bits &= bits - 1u;
-            if (pos < HIVE_LIST_CAP) rowbuf[wv][pos] = (int16_t)(cell * 11u + s);
-            ++pos;
-        }
-        total += __shfl(incl, 63);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    reinterpret_cast<unsigned long long *>(list + b * HIVE_LIST_CAP)[lane] = reinterpret_cast<const unsigned long long *>(rowbuf[wv])[lane];
+    build_id_list(dest[wv], idmask[wv], rowbuf[wv], list + b * HIVE_LIST_CAP, lane);
 }
 
 // value encoders for the plane writer
@@ -652,67 +695,84 @@ template <> struct PlaneVal<bf16_tag> {
     static __device__ __forceinline__ uint32_t of(unsigned v) { return __float_as_uint((float)v) >> 16; }   // v <= 255: exact
 };
 
-// Packed features (56 bits per cell) + history boards + turn -> the plane tensor.  One thread
-// writes 8 consecutive elements (16 B of f16/bf16, 32 B of f32); pure streaming store kernel.
+constexpr long long kExpandMaxBlocks = 256 * 16;      // 16 workgroups of 4 waves per CU keep every CU's store queue full
+
+// Packed features (56 bits per cell) + history boards + turn -> the plane tensor (GamePlay.encode_board's output,
+// env_hive.py:320-447); pure streaming-store kernel.  A workgroup takes whole boards (grid-stride).  Per board: 144
+// threads complete the cells' 56-bit words in LDS (packed features | the eight history bits of planes 36..43, read from
+// the history bitboards: env_hive.py:431-434) -- one barrier, double-buffered --, then thread t < 252 writes the four
+// 16-byte (f16 / bf16; 32-byte f32) items t, t + 252, t + 504, t + 756 of the board: consecutive lanes write consecutive
+// pieces, nothing is divided by a runtime value, and no global load sits between a thread and its stores.
+// (One workgroup per 256 items with per-item history loads ran at 2.0 TB/s of 6.9 the card stores: profiles/r03_encode.md.)
 template <int DT, int LAYOUT>
 __global__ void __launch_bounds__(256)
 hive_expand_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restrict__ hist,
                    const unsigned long long *__restrict__ feat, int n, void *__restrict__ planes)
 {
     using V = typename std::conditional<DT == 0, float, typename std::conditional<DT == 1, half_tag, bf16_tag>::type>::type;
-    constexpr int kItems = kCells * HIVE_PLANES / 8;
-    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long b = g / kItems;
-    if (b >= n) return;
-    const int e0 = (int)(g - b * kItems) * 8;
+    constexpr int kItems = kCells * HIVE_PLANES / 8;      // 1008 items of 8 elements per board = 4 x 252
+    __shared__ unsigned long long full[2][kCells];
     const uint32_t one = PlaneVal<V>::one();
-    const uint32_t meta = reinterpret_cast<const uint32_t *>(&boards[b])[8];    // bytes 32..35
-    const unsigned turn = (meta >> 8) & 0xFFu, hl = meta >> 24;
-    const int persp = (turn & 1u) ? 0 : 1;
-    const unsigned hlen = persp == 0 ? (hl & 15u) : (hl >> 4);
-    const uint32_t tv = PlaneVal<V>::of(turn);
-    uint32_t v[8];
-    if (LAYOUT == HIVE_HWC) {
-        const int cell = e0 / HIVE_PLANES, p0 = e0 - cell * HIVE_PLANES;
-        unsigned bits8 = (unsigned)(feat[b * kCells + cell] >> p0) & 0xFFu;
-        if (p0 >= 32 && p0 < 48 && hist != nullptr) {
-            // history planes 36..43 = (own, enemy) occupancy 1..4 encodes ago (env_hive.py:431-434)
-            unsigned wi, bit;
-            cell_word_bit((unsigned)cell, wi, bit);
-            HIVE_UNROLL for (int k = 0; k < 8; ++k) {
-                int p = p0 + k;
-                if (p >= 36 && p < 44 && (unsigned)((p - 36) >> 1) < hlen)
-                    bits8 |= ((hist[b].m[persp][(p - 36) >> 1][(p - 36) & 1][wi] >> bit) & 1u) << k;
-            }
+    const int tid = threadIdx.x;
+    int buf = 0;
+    // the next board's record bytes and packed word are requested one board ahead, so that their latency runs under this
+    // board's stores
+    uint32_t meta_n = 0u;
+    unsigned long long word_n = 0ull;
+    if ((long long)blockIdx.x < n) {
+        meta_n = reinterpret_cast<const uint32_t *>(&boards[blockIdx.x])[8];    // bytes 32..35
+        if (tid < kCells) word_n = feat[(long long)blockIdx.x * kCells + tid];
+    }
+    for (long long b = blockIdx.x; b < n; b += gridDim.x, buf ^= 1) {
+        const uint32_t meta = meta_n;
+        unsigned long long w = word_n;
+        const long long bn = b + gridDim.x;
+        if (bn < n) {
+            meta_n = reinterpret_cast<const uint32_t *>(&boards[bn])[8];
+            if (tid < kCells) word_n = feat[bn * kCells + tid];
         }
-        HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = ((bits8 >> k) & 1u) ? one : 0u;
-        if (p0 == 24) v[7] = tv;      // plane 31 = raw turn number (env_hive.py:331)
-    } else {
-        const int p = e0 / kCells, c0 = e0 - p * kCells;
-        if (p >= 36 && p < 44) {
-            unsigned hb = 0u;
-            if (hist != nullptr && (unsigned)((p - 36) >> 1) < hlen) {
-                const uint32_t *hw = hist[b].m[persp][(p - 36) >> 1][(p - 36) & 1];
-                HIVE_UNROLL for (int k = 0; k < 8; ++k) {
-                    unsigned wi, bit;
-                    cell_word_bit((unsigned)(c0 + k), wi, bit);
-                    hb |= ((hw[wi] >> bit) & 1u) << k;
+        const unsigned turn = (meta >> 8) & 0xFFu, hl = meta >> 24;
+        const int persp = (turn & 1u) ? 0 : 1;
+        const unsigned hlen = persp == 0 ? (hl & 15u) : (hl >> 4);
+        const uint32_t tv = PlaneVal<V>::of(turn);
+        if (tid < kCells) {
+            if (hist != nullptr) {
+                unsigned wi, bit;
+                cell_word_bit((unsigned)tid, wi, bit);
+                // history planes 36..43 = (own, enemy) occupancy 1..4 encodes ago
+                for (unsigned age = 0; age < hlen && age < 4u; ++age) {
+                    w |= (unsigned long long)((hist[b].m[persp][age][0][wi] >> bit) & 1u) << (36u + 2u * age);
+                    w |= (unsigned long long)((hist[b].m[persp][age][1][wi] >> bit) & 1u) << (37u + 2u * age);
                 }
             }
-            HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = ((hb >> k) & 1u) ? one : 0u;
-        } else {
-            HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = ((feat[b * kCells + c0 + k] >> p) & 1ull) ? one : 0u;
+            full[buf][tid] = w;
         }
-        if (p == 31) { HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = tv; }
-    }
-    const long long eoff = b * (long long)(kCells * HIVE_PLANES) + e0;
-    if (DT == 0) {
-        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<float *>(planes) + eoff);
-        dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
-        dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
-    } else {
-        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(planes) + eoff);
-        dst[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+        __syncthreads();       // (the other buffer is rewritten only after the NEXT barrier: no second one needed)
+        if (tid < kItems / 4) {
+            HIVE_UNROLL for (int j = 0; j < 4; ++j) {
+                const int e0 = (tid + j * (kItems / 4)) * 8;
+                uint32_t v[8];
+                if (LAYOUT == HIVE_HWC) {
+                    const int cell = e0 / HIVE_PLANES, p0 = e0 - cell * HIVE_PLANES;
+                    const unsigned bits8 = (unsigned)(full[buf][cell] >> p0) & 0xFFu;
+                    HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = ((bits8 >> k) & 1u) ? one : 0u;
+                    if (p0 == 24) v[7] = tv;      // plane 31 = raw turn number (env_hive.py:331)
+                } else {
+                    const int pl = e0 / kCells, c0 = e0 - pl * kCells;
+                    HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = ((full[buf][c0 + k] >> pl) & 1ull) ? one : 0u;
+                    if (pl == 31) { HIVE_UNROLL for (int k = 0; k < 8; ++k) v[k] = tv; }
+                }
+                const long long eoff = b * (long long)(kCells * HIVE_PLANES) + e0;
+                if (DT == 0) {
+                    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<float *>(planes) + eoff);
+                    dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
+                    dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
+                } else {
+                    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(planes) + eoff);
+                    dst[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+                }
+            }
+        }
     }
 }
 
@@ -847,14 +907,15 @@ static int launch_pieces(const HiveBoard *boards, int n, uint32_t *mask, int32_t
 {
     if (n <= 0 || boards == nullptr) return fail(HIVE_E_ARG, "movegen: n <= 0 or boards == NULL");
     if (list != nullptr && mask == nullptr) return fail(HIVE_E_ARG, "movegen: the id list needs the mask buffer too");
-    hipLaunchKernelGGL((hive_piece_kernel<false>), dim3((unsigned)((n + 15) / 16)), dim3(NW * 64), 0, stream, boards, n, mask,
-                       count, (unsigned long long *)nullptr);
+    if (list != nullptr && ((uintptr_t)list & 7u) != 0)
+        return fail(HIVE_E_ARG, "movegen: the id list must be 8-byte aligned (rows leave as 8-byte stores)");
+    if (list != nullptr)      // mask, count and the sorted id lists in ONE launch (hive_piece_kernel<false, true>)
+        hipLaunchKernelGGL((hive_piece_kernel<false, true>), dim3((unsigned)((n + 15) / 16)), dim3(NW * 64), 0, stream, boards, n,
+                           mask, count, (unsigned long long *)nullptr, list);
+    else
+        hipLaunchKernelGGL((hive_piece_kernel<false, false>), dim3((unsigned)((n + 15) / 16)), dim3(NW * 64), 0, stream, boards, n,
+                           mask, count, (unsigned long long *)nullptr, (int16_t *)nullptr);
     HIP_TRY(hipGetLastError());
-    if (list != nullptr) {
-        hipLaunchKernelGGL(hive_list_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream,
-                           mask, n, list);
-        HIP_TRY(hipGetLastError());
-    }
     return HIVE_OK;
 }
 
@@ -864,11 +925,10 @@ static int launch_encode(const HiveBoard *boards, const HiveHistory *hist, int n
     if (n <= 0 || boards == nullptr || planes == nullptr || feat == nullptr)
         return fail(HIVE_E_ARG, "encode: n <= 0 or a NULL buffer");
     if (dtype < 0 || dtype > 2 || layout < 0 || layout > 1) return fail(HIVE_E_ARG, "encode: unknown dtype/layout");
-    hipLaunchKernelGGL((hive_piece_kernel<true>), dim3((unsigned)((n + 7) / 8)), dim3(NW * 64), 0, stream, boards, n, mask,
-                       count, feat);
+    hipLaunchKernelGGL((hive_piece_kernel<true, false>), dim3((unsigned)((n + 7) / 8)), dim3(NW * 64), 0, stream, boards, n, mask,
+                       count, feat, (int16_t *)nullptr);
     HIP_TRY(hipGetLastError());
-    const long long items = (long long)n * (kCells * HIVE_PLANES / 8);
-    dim3 grid((unsigned)((items + 255) / 256));
+    dim3 grid((unsigned)std::min<long long>(n, kExpandMaxBlocks));
 #define HIVE_EXP_CASE(DT, LY)                                                                                  \
     if (dtype == DT && layout == LY)                                                                           \
         hipLaunchKernelGGL((hive_expand_kernel<DT, LY>), grid, dim3(256), 0, stream, boards, hist, feat, n, planes);
@@ -897,8 +957,7 @@ int hive_expand_launch(const HiveBoard *boards, const HiveHistory *hist, const v
         return fail(HIVE_E_ARG, "expand: n <= 0 or a NULL buffer");
     const int dt = (int)dtype, ly = (int)layout;
     if (dt < 0 || dt > 2 || ly < 0 || ly > 1) return fail(HIVE_E_ARG, "expand: unknown dtype/layout");
-    const long long items = (long long)n * (kCells * HIVE_PLANES / 8);
-    dim3 grid((unsigned)((items + 255) / 256));
+    dim3 grid((unsigned)std::min<long long>(n, kExpandMaxBlocks));
     const unsigned long long *feat = (const unsigned long long *)features;
 #define HIVE_EXP_CASE(DT, LY)                                                                                  \
     if (dt == DT && ly == LY)                                                                                  \
@@ -924,6 +983,18 @@ int hive_step_launch(HiveBoard *boards, HiveHistory *hist, int n, const int32_t 
     if (n <= 0 || boards == nullptr || actions == nullptr) return fail(HIVE_E_ARG, "step: bad argument");
     hipLaunchKernelGGL(hive_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boards, hist,
                        n, actions, legal_mask, (unsigned long long *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_step_launch_counted(HiveBoard *boards, HiveHistory *hist, int n, const int32_t *actions, const uint32_t *legal_mask,
+                             unsigned long long *illegal_count, void *stream)
+{
+    if (n <= 0 || boards == nullptr || actions == nullptr) return fail(HIVE_E_ARG, "step: bad argument");
+    if (legal_mask == nullptr && illegal_count != nullptr)
+        return fail(HIVE_E_ARG, "step: counting refused actions needs the legal mask they are tested against");
+    hipLaunchKernelGGL(hive_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boards, hist,
+                       n, actions, legal_mask, illegal_count);
     HIP_TRY(hipGetLastError());
     return HIVE_OK;
 }
@@ -1014,10 +1085,10 @@ int hive_batch_reset(HiveBatch *h, const int32_t *idx, int k)
 static int ensure_legal(HiveBatch *h, bool want_list)
 {
     if (!h->legal_valid) {
-        int rc = launch_pieces(h->boards, h->n, h->legal, h->legal_count, nullptr, h->stream);
+        int rc = launch_pieces(h->boards, h->n, h->legal, h->legal_count, want_list ? h->legal_list : nullptr, h->stream);
         if (rc != HIVE_OK) return rc;
         h->legal_valid = true;
-        h->list_valid = false;
+        h->list_valid = want_list;
     }
     if (want_list && !h->list_valid) {
         hipLaunchKernelGGL(hive_list_kernel, dim3((unsigned)((h->n + 3) / 4)), dim3(256), 0, h->stream, h->legal, h->n,

@@ -173,6 +173,10 @@ def dataset_tensors_gpu(games, device=None, dtype=None, layout="chw"):
     rows = [(g[0], p, sum(1 for q in g[1] if q[5] == p[5]), sum(1 for q in g[1][:k + 1] if q[5] == p[5]))
             for g in games for k, p in enumerate(g[1])]
     n = len(rows)
+    if n == 0:                      # nothing to widen (hive_expand_launch refuses n <= 0)
+        shape = (0, 56, 12, 12) if layout == "chw" else (0, 12, 12, 56)
+        return (torch.zeros(shape, dtype=dtype, device=dev), torch.zeros((0, 1584), dtype=torch.float32, device=dev),
+                torch.zeros((0,), dtype=torch.float32, device=dev))
     boards = np.zeros((n, 64), dtype=np.uint8)
     hist = np.zeros((n, 2, 4, 2, 6), dtype=np.uint32)
     feat = np.zeros((n, 144), dtype=np.uint64)

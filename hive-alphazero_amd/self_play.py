@@ -17,25 +17,64 @@ import os
 import queue as queue_mod
 import time
 
-from . import records
-from .dist import game_id_stream
+
+def child_device_env(gpu, environ=None):
+    """Environment changes that pin a child process to logical GPU `gpu` of THIS process: {name: value or None (= unset)}.
+
+    The parent counts devices inside whatever mask it inherited (a scheduler's HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES
+    = "4,5,6,7" makes them logical 0..3), so the child's mask is the gpu-th entry of that mask, not the bare index; the
+    CUDA_ alias is cleared so that it cannot contradict it.  (ROCR_VISIBLE_DEVICES acts one layer below and is inherited
+    unchanged: HIP's indices are already relative to it.)"""
+    environ = os.environ if environ is None else environ
+    mask = environ.get("HIP_VISIBLE_DEVICES") or environ.get("CUDA_VISIBLE_DEVICES")
+    if mask:
+        entries = [e.strip() for e in mask.split(",") if e.strip()]
+        if gpu >= len(entries):
+            raise RuntimeError(f"SelfPlayWorker: GPU {gpu} is outside the inherited device mask {mask!r}")
+        value = entries[gpu]
+    else:
+        value = str(gpu)
+    return {"HIP_VISIBLE_DEVICES": value, "CUDA_VISIBLE_DEVICES": None}
+
+
+def _child_main(env, worker, rank, world, cfg, out):
+    """Entry point of a spawned child: pin the device BEFORE anything imports torch / touches HIP, then run the worker."""
+    for name, value in env.items():
+        if value is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = value
+    worker(rank, world, cfg, out)
 
 
 def _game_worker(rank, world, cfg, out):
-    """One GPU's producer (child process; the parent exported HIP_VISIBLE_DEVICES = this rank's GPU for it)."""
+    """One GPU's producer (child process; _child_main has set HIP_VISIBLE_DEVICES = this rank's GPU)."""
     import torch
     from . import mcts
     from .alpha_net import ChessNet, InferenceNet
+    from .dist import game_id_stream
     try:
         torch.manual_seed(cfg["net_seed"])
         net = ChessNet()
         if cfg.get("checkpoint"):
             # the reference's checkpoints are {'state_dict': ...} (self_play.py:92-96); tensors only, nothing executed
             net.load_state_dict(torch.load(cfg["checkpoint"], map_location="cpu", weights_only=True)["state_dict"])
-        evaluator = InferenceNet(net.cuda().eval(), dtype=torch.bfloat16)
+        dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[cfg.get("net_dtype", "bf16")]
+        evaluator = InferenceNet(net.cuda().eval(), dtype=dtype)
+        if cfg.get("warmup"):
+            # one ply of a throw-away engine: HIP-graph capture and GEMM tuning of this batch size happen here, once per
+            # process, before the first game is on the clock
+            warm = mcts.SelfPlay(cfg["games_per_gpu"], cfg["sims"], evaluator, device=0, slots=cfg["slots"], seed=cfg["seed"],
+                                 keep_records=False)
+            warm.play_ply()
+            torch.cuda.synchronize()
+            warm.close()
         ids = game_id_stream(rank, world, cfg["total_games"])
+        # games that start in lock step mostly end on the same ply (the 55-turn cap): every slot's game can be waiting in
+        # finished_games at once, so the keep limit must cover the whole batch (this loop drains after every ply)
         sp = mcts.SelfPlay(cfg["games_per_gpu"], cfg["sims"], evaluator, device=0, slots=cfg["slots"], seed=cfg["seed"],
-                           game_ids=ids)
+                           game_ids=ids, max_finished_kept=max(1024, 2 * cfg["games_per_gpu"]))
+        out.put(("ready", rank, time.time(), 0, None))
         while True:
             sp.play_ply()
             for entry in sp.drain_finished():
@@ -46,7 +85,7 @@ def _game_worker(rank, world, cfg, out):
                 break
         illegal, leaves = sp.env.illegal_count(), sp.leaf_histogram()
         sp.close()
-        out.put(("done", rank, sp.finished, illegal, leaves))
+        out.put(("done", rank, sp.finished, illegal, leaves, {"dropped": sp.dropped_games, "unrecorded": sp.unrecorded_games}))
     except BaseException as exc:                 # the parent must not wait for a rank that died
         out.put(("error", rank, repr(exc), 0, None))
         raise
@@ -54,7 +93,8 @@ def _game_worker(rank, world, cfg, out):
 
 class SelfPlayWorker:
     def __init__(self, total_games, games_per_gpu=1024, sims=50, gpus=None, seed=0, net_seed=0, checkpoint=None, slots=1,
-                 datapath="../dataSelf", games_per_file=100, report_every=10, worker=_game_worker, log=print, row_format="json"):
+                 datapath="../dataSelf", games_per_file=100, report_every=10, worker=_game_worker, log=print, row_format="json",
+                 net_dtype="bf16", warmup=False):
         """row_format "json": results / files hold the reference's rows (play_<ts>.json, self_play.py:100-112);
         "compact": results hold the games as SelfPlay collects them and the files are play_<ts>.npz (records.save_games;
         records.dataset_from_games / rows_from_game expand them) -- the format that keeps up with a node of GPUs."""
@@ -62,7 +102,8 @@ class SelfPlayWorker:
             raise ValueError("row_format must be 'json' or 'compact'")
         self.row_format = row_format
         self.cfg = {"total_games": int(total_games), "games_per_gpu": int(games_per_gpu), "sims": int(sims), "seed": int(seed),
-                    "net_seed": int(net_seed), "checkpoint": checkpoint, "slots": int(slots), "row_format": row_format}
+                    "net_seed": int(net_seed), "checkpoint": checkpoint, "slots": int(slots), "row_format": row_format,
+                    "net_dtype": net_dtype, "warmup": bool(warmup)}
         if gpus is None:
             import torch
             gpus = list(range(torch.cuda.device_count()))      # counting devices does not initialise HIP
@@ -75,24 +116,20 @@ class SelfPlayWorker:
         self.win_lose, self.game_lens, self.files = [], [], []
         self.buffer = []
         self.leaf_kinds = {}         # leaves of every simulation by kind, summed over the ranks (mcts.LEAF_KINDS)
+        self.ready_at = {}           # rank -> wall-clock time its engine was built (network on the GPU, trees allocated)
 
     # ---------------------------------------------------------------- parent side
     def _spawn(self, out):
         ctx = mp.get_context("spawn")
         procs = []
         world = len(self.gpus)
-        saved = os.environ.get("HIP_VISIBLE_DEVICES")
-        try:
-            for rank, gpu in enumerate(self.gpus):
-                os.environ["HIP_VISIBLE_DEVICES"] = str(gpu)    # inherited at spawn: set before the child's first HIP call
-                p = ctx.Process(target=self._worker, args=(rank, world, self.cfg, out), daemon=True)
-                p.start()
-                procs.append(p)
-        finally:
-            if saved is None:
-                os.environ.pop("HIP_VISIBLE_DEVICES", None)
-            else:
-                os.environ["HIP_VISIBLE_DEVICES"] = saved
+        for rank, gpu in enumerate(self.gpus):
+            # the device mask travels as an argument and is applied by the child itself before it imports torch: the
+            # parent's own environment is never touched
+            p = ctx.Process(target=_child_main, args=(child_device_env(gpu), self._worker, rank, world, self.cfg, out),
+                            daemon=True)
+            p.start()
+            procs.append(p)
         return procs
 
     def _take(self, game_id, value_white, rows):
@@ -113,6 +150,7 @@ class SelfPlayWorker:
                       f"White_Win % {wins / n:.2f} --- ")
 
     def flush_buffer(self):
+        from . import records
         if self.buffer and self.datapath:
             if self.row_format == "compact":
                 import datetime
@@ -124,37 +162,55 @@ class SelfPlayWorker:
         self.buffer = []
 
     def start(self, timeout_s=None):
-        """Play games 0 .. total_games-1; returns {game id: (value_white, rows)} ordered by game id."""
+        """Play games 0 .. total_games-1; returns {game id: (value_white, rows)} ordered by game id.  Raises if a rank
+        fails, if the env refused a move, if a rank dropped or could not record a game, or if any game id is missing."""
+        from . import records  # noqa: F401  (flush_buffer uses it; imported here so that spawning stays torch-free)
         ctx = mp.get_context("spawn")
         out = ctx.Queue()
         procs = self._spawn(out)
         pending, t0 = set(range(len(procs))), time.time()
+        lost = {}
+        ok = False
         try:
             while pending:
+                if timeout_s is not None and time.time() - t0 > timeout_s:       # checked on every turn of the loop
+                    raise TimeoutError(f"SelfPlayWorker.start: ranks {sorted(pending)} still running after {timeout_s} s")
                 try:
                     msg = out.get(timeout=1.0)
                 except queue_mod.Empty:
                     dead = [r for r in pending if not procs[r].is_alive()]
                     if dead and out.empty():
                         raise RuntimeError(f"self-play rank(s) {dead} exited without reporting")
-                    if timeout_s is not None and time.time() - t0 > timeout_s:
-                        raise TimeoutError("SelfPlayWorker.start: timeout")
                     continue
                 if msg[0] == "game":
                     self._take(msg[2], msg[3], msg[4])
+                elif msg[0] == "ready":
+                    self.ready_at[msg[1]] = msg[2]
                 elif msg[0] == "done":
                     pending.discard(msg[1])
                     for kind, count in (msg[4] or {}).items():
                         self.leaf_kinds[kind] = self.leaf_kinds.get(kind, 0) + count
                     if msg[3]:
                         raise RuntimeError(f"rank {msg[1]}: the env refused {msg[3]} moves of the search")
+                    extra = msg[5] if len(msg) > 5 and msg[5] else {}
+                    if extra.get("dropped") or extra.get("unrecorded"):
+                        lost[msg[1]] = extra
                 else:
                     raise RuntimeError(f"self-play rank {msg[1]} failed: {msg[2]}")
+            ok = True
         finally:
+            if not ok:
+                for p in procs:                   # a failed run: the children may be blocked on a queue nobody drains
+                    if p.is_alive():
+                        p.terminate()
             for p in procs:
                 p.join(timeout=10)
                 if p.is_alive():
                     p.terminate()
         self.flush_buffer()
         self.results = dict(sorted(self.results.items()))
+        missing = sorted(set(range(self.cfg["total_games"])) - set(self.results))
+        if lost or missing:
+            raise RuntimeError(f"SelfPlayWorker: games lost -- per rank {lost}, missing ids {missing[:16]}"
+                               f"{' ...' if len(missing) > 16 else ''} ({len(missing)} of {self.cfg['total_games']})")
         return self.results

@@ -137,6 +137,9 @@ int hive_batch_import(HiveBatch *h, const HiveBoard *boards, const HiveHistory *
  * positions live in node pools).  Same semantics as the batch calls above. */
 int hive_movegen_launch(const HiveBoard *boards, int n, uint32_t *mask, int32_t *count,
                         int16_t *list, void *stream);
+/* (list, when given, must be 8-byte aligned -- its rows of HIVE_LIST_CAP ids leave the kernel as 8-byte stores; a
+ * misaligned pointer is refused with HIVE_E_ARG.  With list != NULL the mask, the counts and the sorted id lists are
+ * produced by ONE launch.) */
 /* workspace = device scratch of n * HIVE_CELLS * 8 bytes (the packed 56-bit-per-cell features). */
 int hive_encode_launch(const HiveBoard *boards, const HiveHistory *hist, int n, void *planes,
                        HiveDType dtype, HiveLayout layout, void *workspace, void *stream);
@@ -154,6 +157,13 @@ int hive_terminal_launch(const HiveBoard *boards, int n, int8_t *over, int8_t *w
  * NULL when the actions are known to be legal (they come out of the search's own edge lists). */
 int hive_step_launch(HiveBoard *boards, HiveHistory *hist, int n, const int32_t *actions, const uint32_t *legal_mask,
                      void *stream);
+/* The same with the batch form's contract on refused moves (hive_batch_step / hive_batch_illegal_count): an action that
+ * is not in its board's legal_mask row leaves that board unchanged AND adds one to *illegal_count (a device counter the
+ * caller owns and zeroes; it accumulates over calls).  hive_step_launch refuses such actions silently; with
+ * legal_mask == NULL nothing is tested and illegal_count must be NULL too.  (The reference applies illegal moves
+ * blindly: its `assert check` is commented out, env_hive.py:129-144.) */
+int hive_step_launch_counted(HiveBoard *boards, HiveHistory *hist, int n, const int32_t *actions, const uint32_t *legal_mask,
+                             unsigned long long *illegal_count, void *stream);
 /* Everything the tree search needs about n leaf positions in one call: planes (as hive_encode_launch),
  * legal mask / count (may be NULL) and game-over flags (may be NULL). */
 int hive_leaf_launch(const HiveBoard *boards, const HiveHistory *hist, int n, void *planes, HiveDType dtype,

@@ -33,6 +33,27 @@ int hive_nn_conv3x3(const void *x, int cin, const void *w, const float *bias, co
 int hive_nn_resblock(const void *x, const void *w1, const float *b1, const void *w2, const float *b2, void *y,
                      int batch, void *stream);
 
+/* The same two entry points for either 16-bit format of the matrix cores: dtype = HIVE_BF16 or HIVE_F16
+ * (include/hive_abi.h HiveDType); x, w, residual, y are then all of that type.  fp16 carries three more mantissa bits
+ * than bf16 at the same MFMA rate (the planes are exactly representable in both; BatchNorm-folded weights and the
+ * activations of this network stay far inside fp16's range). */
+int hive_nn_conv3x3_dt(const void *x, int cin, const void *w, const float *bias, const void *residual, void *y,
+                       int batch, int relu, int dtype, void *stream);
+int hive_nn_resblock_dt(const void *x, const void *w1, const float *b1, const void *w2, const float *b2, void *y,
+                        int batch, int dtype, void *stream);
+
+/* The whole residual tower (alpha_net.py:87-99, the loop over res_0 .. res_{nblocks-1}) in ONE launch:
+ *   x, y   [batch][144][256] channels-last (dtype as above); y must not alias x
+ *   w      [2 * nblocks][9][8][16][64][8]: the fragment-major weights of conv1, conv2 of block 0, conv1 of block 1, ...
+ *          back to back (each as hive_nn_conv3x3 reads it);  bias f32 [2 * nblocks][256]
+ * A workgroup keeps its board(s) in LDS across all blocks; per block only the skip operand is re-read from, and the
+ * block's output written to, global memory (y holds every block's output in turn; at return, the tower's).
+ * boards_per_group: 1 = one board per workgroup (two workgroups per CU); 2 = two boards per workgroup (one per CU)
+ * sharing every weight fragment fetched from L2 (half the weight stream); 0 = choose by batch size.
+ * Results are bit-identical to nblocks calls of hive_nn_resblock_dt. */
+int hive_nn_tower(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
+                  int boards_per_group, void *stream);
+
 /* Training-mode BatchNorm2d + optional skip connection + optional ReLU of the 256-channel tower, forward and
  * backward (alpha_net.py:25-54 as executed by the training step alpha_net.py:117-162), channels-last bf16:
  *   forward : y = act( (x - mean_c) / sqrt(var_c + eps) * gamma_c + beta_c (+ residual) ), batch statistics over all

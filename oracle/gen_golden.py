@@ -25,6 +25,8 @@ Fixture families:
   mcts_deep.json.gz  the same at 600 simulations without root noise: searches deep enough
                      to run through dict entries shared by two move orders
   net.json           ChessNet seeded-init output checksums
+  net_wide.npz       ChessNet outputs (full p[1584], v) on 64 golden positions, for the seeded init and for the same
+                     init with peaked policy / stretched value heads
 """
 import argparse
 import gzip
@@ -511,6 +513,65 @@ def cmd_net(a):
     print("net.json written", out["v"])
 
 
+NET_WIDE_PEAK = {"policy_scale": 30.0, "value_scale": 6.0, "value_shift": 2.9}
+
+
+def net_wide_picks(games):
+    """64 positions of the `games_full` fixture: an early and a late ply of each of the first 32 games."""
+    picks = []
+    for gi in range(32):
+        n = len(games[gi]["plies"])
+        for ply in (5 + gi % 7, n - 3 - (gi % 5)):
+            picks.append((gi, max(0, min(n - 1, ply))))
+    return picks
+
+
+def peak_state_dict(sd, peak=NET_WIDE_PEAK):
+    """The second weight set of the `net_wide` fixture: the seeded init with the policy head's logits scaled (priors
+    become peaked: a random-init network is near-uniform, max p ~ 1e-3) and the value head's output stretched and
+    centred (v spreads over (-1, 1) instead of [-0.9, -0.1]).  In place; tests/test_net.py applies the same edit."""
+    sd["outblock.fc.weight"] *= peak["policy_scale"]
+    sd["outblock.fc.bias"] *= peak["policy_scale"]
+    sd["outblock.fc2.weight"] *= peak["value_scale"]
+    sd["outblock.fc2.bias"].mul_(peak["value_scale"]).add_(peak["value_shift"])
+    return sd
+
+
+def cmd_net_wide(a):
+    """alpha_zero/alpha_net.py::ChessNet (the TRUE reference, CPU fp32) on 64 golden positions under two weight sets --
+    the seeded init and the same init with peaked heads -- full p[1584] and v per position -> tests/golden/net_wide.npz.
+    Gives the reduced-precision engines (bf16 / fp16 leaf evaluator) a signal larger than their tolerance."""
+    import torch
+    from alpha_zero.alpha_net import ChessNet as RefNet
+    with gzip.open(os.path.join(GOLD, "games_full.json.gz"), "rt") as f:
+        games = json.load(f)["games"]
+    picks = net_wide_picks(games)
+    xs = []
+    for gi, ply in picks:
+        rec = games[gi]["plies"][ply]
+        pl = np.zeros((12, 12, 56), dtype=np.float32)
+        pl.reshape(-1)[rec["planes"]] = 1.0
+        pl[:, :, 31] = rec["t"]
+        xs.append(pl.transpose(2, 0, 1))
+    x = torch.from_numpy(np.ascontiguousarray(np.stack(xs))).contiguous()
+    out = {"picks": np.asarray(picks, dtype=np.int32), "seed": np.int32(a.seed),
+           "peak": np.asarray([NET_WIDE_PEAK["policy_scale"], NET_WIDE_PEAK["value_scale"], NET_WIDE_PEAK["value_shift"]], dtype=np.float64)}
+    for tag in ("init", "peak"):
+        torch.manual_seed(a.seed)
+        ref = RefNet().eval()
+        if tag == "peak":
+            ref.load_state_dict(peak_state_dict(ref.state_dict()))
+        with torch.no_grad():
+            p, v = ref(x)
+        out["p_" + tag] = p.numpy().astype(np.float32)
+        out["v_" + tag] = v.view(-1).numpy().astype(np.float32)
+        print(tag, "max p: median %.4f min %.4f max %.4f;  v min %.3f max %.3f" % (
+            float(p.max(1).values.median()), float(p.max(1).values.min()), float(p.max(1).values.max()),
+            float(v.min()), float(v.max())))
+    np.savez_compressed(os.path.join(GOLD, "net_wide.npz"), **out)
+    print("net_wide.npz written:", os.path.getsize(os.path.join(GOLD, "net_wide.npz")), "bytes")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -529,6 +590,8 @@ if __name__ == "__main__":
     sub.add_parser("train")
     pn = sub.add_parser("net")
     pn.add_argument("--seed", type=int, default=0)
+    pw = sub.add_parser("net_wide")
+    pw.add_argument("--seed", type=int, default=0)
     pu = sub.add_parser("uct")
     pu.add_argument("--reads", type=int, default=40)
     pu.add_argument("--deep", action="store_true", help="write uct_deep.json: late positions (use --reads 120)")
@@ -537,5 +600,5 @@ if __name__ == "__main__":
     ps.add_argument("--seed", type=int, default=4)
     sub.add_parser("sl")
     a = ap.parse_args()
-    {"tables": cmd_tables, "games": cmd_games, "mcts": cmd_mcts, "mcts_deep": cmd_mcts_deep, "train": cmd_train, "net": cmd_net, "uct": cmd_uct,
+    {"tables": cmd_tables, "games": cmd_games, "mcts": cmd_mcts, "mcts_deep": cmd_mcts_deep, "train": cmd_train, "net": cmd_net, "net_wide": cmd_net_wide, "uct": cmd_uct,
      "selfplay": cmd_selfplay, "sl": cmd_sl}[a.cmd](a)

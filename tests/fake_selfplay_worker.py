@@ -20,10 +20,19 @@ def worker(rank, world, cfg, out):
     from hive_alphazero_amd.dist import game_id_stream
     ids = list(game_id_stream(rank, world, cfg["total_games"]))
     gpu = os.environ.get("HIP_VISIBLE_DEVICES")
+    assert "CUDA_VISIBLE_DEVICES" not in os.environ          # the alias must not be able to contradict the mask
+    if cfg["seed"] == 666 and rank == world - 1:
+        ids = ids[:-1]                                        # a rank that loses a game (and says so)
+        lost = {"dropped": 1, "unrecorded": 0}
+    elif cfg["seed"] == 667 and rank == 0:
+        ids = ids[1:]                                         # a rank that loses a game silently
+        lost = None
+    else:
+        lost = {"dropped": 0, "unrecorded": 0}
     # finish the games out of order, like lock-step slots do
     order = ids[::2] + ids[1::2]
     for g in order:
         vw, rows = fabricate(cfg["seed"], g)
         rows[0][0].append(gpu)            # smuggle the device assignment out for the test
         out.put(("game", rank, g, vw, rows))
-    out.put(("done", rank, len(ids), 0, {"root_evaluated": len(ids)}))
+    out.put(("done", rank, len(ids), 0, {"root_evaluated": len(ids)}, lost))

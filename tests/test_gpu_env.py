@@ -180,6 +180,63 @@ def test_illegal_action_is_refused(hv):
     B.close()
 
 
+def test_stateless_step_counts_refused_moves(hv):
+    """hive_step_launch_counted: the stateless form of GamePlay.move with the batch form's contract (include/hive_abi.h):
+    an action outside its board's legal mask leaves the board unchanged and is counted; hive_step_launch refuses it
+    silently; the fused movegen launch (mask + count + sorted ids in one kernel) equals the mask-only launch + the
+    separate list kernel of the batch handle; a misaligned id list is refused."""
+    h, batch, packing = hv
+    import ctypes
+    from hive_alphazero_amd import playout
+    from hive_alphazero_amd._lib import HIVE_MASK_WORDS
+    L = h.load()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    n = 300                                                        # not a multiple of the 16-board workgroup
+    boards = playout.random_positions(n, seed=77)
+    hist = torch.zeros((n, 384), dtype=torch.uint8, device="cuda")
+    mask = torch.zeros((n, HIVE_MASK_WORDS), dtype=torch.int32, device="cuda")
+    count = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    lst = torch.full((n, 256), 7, dtype=torch.int16, device="cuda")
+    assert L.hive_movegen_launch(P(boards), n, P(mask), P(count), P(lst), None) == 0          # one fused launch
+    mask2, count2 = torch.zeros_like(mask), torch.zeros_like(count)
+    assert L.hive_movegen_launch(P(boards), n, P(mask2), P(count2), None, None) == 0          # mask-only launch
+    torch.cuda.synchronize()
+    assert torch.equal(mask, mask2) and torch.equal(count, count2)
+    B = batch.BoardBatch(n)
+    B.import_state(boards)
+    m3, c3, l3 = B.legal(want_list=True)
+    assert torch.equal(l3, lst) and torch.equal(c3, count)
+    rows = _mask_rows_to_lists(mask)
+    cnt = count.cpu().numpy()
+    ls = lst.cpu().numpy()
+    for i in range(n):
+        assert ls[i, :cnt[i]].tolist() == rows[i] and np.all(ls[i, cnt[i]:] == -1)
+    odd = lst.view(-1)[1:1 + 256 * 4]                              # 2-byte aligned only
+    assert L.hive_movegen_launch(P(boards), 4, P(mask), P(count), ctypes.c_void_p(odd.data_ptr()), None) == -1
+    assert b"8-byte" in L.hive_last_error()
+    # every third board gets an action that is not in its legal set
+    legal_first = torch.where(count > 0, lst[:, 0].to(torch.int32), torch.full_like(count, -1))
+    acts = legal_first.clone()
+    bad_rows = []
+    for i in range(0, n, 3):
+        if cnt[i] > 0:
+            illegal = next(a for a in range(1584) if a not in set(rows[i]))
+            acts[i] = illegal
+            bad_rows.append(i)
+    counter = torch.zeros((1,), dtype=torch.int64, device="cuda")
+    b1, b2 = boards.clone(), boards.clone()
+    assert L.hive_step_launch_counted(P(b1), P(hist.clone()), n, P(acts), P(mask), P(counter), None) == 0
+    assert L.hive_step_launch(P(b2), P(hist.clone()), n, P(acts), P(mask), None) == 0
+    torch.cuda.synchronize()
+    assert int(counter.item()) == len(bad_rows) > 50
+    assert torch.equal(b1, b2)                                     # same state either way: refused boards unchanged
+    assert torch.equal(b1[bad_rows], boards[bad_rows])
+    moved = [i for i in range(n) if i not in set(bad_rows) and cnt[i] > 0]
+    assert bool((b1[moved, 33] == boards[moved, 33] + 1).all())    # the others advanced one turn
+    assert L.hive_step_launch_counted(P(b1), None, n, P(acts), None, P(counter), None) == -1    # a counter needs a mask
+    B.close()
+
+
 def _oracle_corpus(n, seed):
     """n positions sampled from oracle random playouts (seeded)."""
     from oracle import oracle_py as O

@@ -258,6 +258,34 @@ def test_selfplay_worker_shards_games_by_global_id(tmp_path):
     assert "HIP_VISIBLE_DEVICES" not in os.environ or os.environ["HIP_VISIBLE_DEVICES"] != "1"
 
 
+def test_selfplay_worker_device_masks_and_lost_games(tmp_path, monkeypatch):
+    """The child's device mask is the parent's logical index translated through whatever mask the parent inherited
+    (a scheduler's HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES = "4,5,6,7"), applied by the child itself, the parent's
+    environment untouched; a rank that drops a game -- loudly or silently -- fails the run instead of returning fewer
+    games than promised (self_play.py docstring: 'games 0 .. total_games-1')."""
+    import fake_selfplay_worker as fw
+    from hive_alphazero_amd.self_play import SelfPlayWorker, child_device_env
+    assert child_device_env(1, {}) == {"HIP_VISIBLE_DEVICES": "1", "CUDA_VISIBLE_DEVICES": None}
+    assert child_device_env(2, {"HIP_VISIBLE_DEVICES": "4,5,6,7"})["HIP_VISIBLE_DEVICES"] == "6"
+    assert child_device_env(0, {"CUDA_VISIBLE_DEVICES": "3, 1"})["HIP_VISIBLE_DEVICES"] == "3"
+    assert child_device_env(1, {"HIP_VISIBLE_DEVICES": "7,2", "CUDA_VISIBLE_DEVICES": "0,1"})["HIP_VISIBLE_DEVICES"] == "2"
+    with pytest.raises(RuntimeError):
+        child_device_env(2, {"HIP_VISIBLE_DEVICES": "4,5"})
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "5,3")
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "0,1")
+    w = SelfPlayWorker(total_games=9, games_per_gpu=4, sims=2, gpus=[0, 1], seed=7, datapath=None, games_per_file=0,
+                       report_every=0, worker=fw.worker, log=lambda *_: None)
+    res = w.start(timeout_s=120)
+    lo1 = 5                                                   # shard(9, 1, 2)
+    assert [rows[0][0][2] for _, (vw, rows) in sorted(res.items())] == ["5" if g < lo1 else "3" for g in range(9)]
+    assert os.environ["HIP_VISIBLE_DEVICES"] == "5,3" and os.environ["CUDA_VISIBLE_DEVICES"] == "0,1"
+    for seed in (666, 667):
+        w = SelfPlayWorker(total_games=9, games_per_gpu=4, sims=2, gpus=[0, 1], seed=seed, datapath=None, games_per_file=0,
+                           report_every=0, worker=fw.worker, log=lambda *_: None)
+        with pytest.raises(RuntimeError, match="games lost"):
+            w.start(timeout_s=120)
+
+
 def test_compact_game_files_expand_to_the_reference_rows(tmp_path):
     """records.save_games / load_games keep finished games as they leave the GPU (packed 56-bit features, history bitboards,
     sparse policy); rows_from_game and dataset_from_games must yield exactly what the JSON route (game_entries ->
