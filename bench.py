@@ -21,14 +21,25 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_BOARD = 262          # 64 B HiveBoard read + 198 B (1584-bit) legal mask written, SURVEY.md 8d
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
-# HBM bytes per board from the PMC passes in profiles/r02_movegen_pmc_traffic.md: (2 x FETCH_SIZE + WRITE_SIZE) KiB
-# per 4096-board launch = 1,622,036 B (gfx950 FETCH_SIZE correction applied); not measurable from inside bench.py
-MOVEGEN_TRAFFIC_BYTES_PER_BOARD = 396
-MOVEGEN_TRAFFIC_SOURCE = "profiles/r02_movegen_pmc_traffic.md (separate rocprofv3 --pmc passes of this command; not measured in-run)"
-# the bound that actually binds: 489 VALU wave-instructions per board (PMC, profiles/r01_movegen_pmc_valu.md), each
-# occupying one of the 1024 SIMDs for 4 cycles at 2.4 GHz
-MOVEGEN_VALU_PER_BOARD = 489
-VALU_ISSUE_PEAK_MBOARDS = 1024 * 2.4e9 / (MOVEGEN_VALU_PER_BOARD * 4) / 1e6
+
+
+def movegen_counters():
+    """PMC counts of the movegen kernel per 4096-board dispatch (instructions, HBM bytes), read from the newest
+    profiles/r*_movegen_counters.json -- the file the round's rocprofv3 passes produced (tools/dev/prof_r03.sh); they
+    cannot be measured from inside this process.  Returns None if no such file is in the tree."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_movegen_counters.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        c = json.load(f)
+    k = c["hive_piece_kernel<false,false>"]
+    n = c["boards_per_dispatch"]
+    valu = k["SQ_INSTS_VALU"] / n
+    return {"file": os.path.relpath(files[-1], ROOT), "source": c["source"],
+            "traffic_bytes_per_board": (c["fetch_size_correction"] * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0 / n,
+            "valu_per_board": valu,
+            "valu_issue_peak_mboards": 1024 * 2.4e9 / (valu * 4) / 1e6}      # 1024 SIMDs, 4 cycles per wave-instruction
 
 
 def host_cores(cap=16):
@@ -115,9 +126,35 @@ def selfplay_measure(args, rank, local_rank, world):
     from hive_alphazero_amd import mcts
     from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
     torch.manual_seed(0)
-    net = InferenceNet(ChessNet().cuda().eval(), dtype=torch.bfloat16)
+    base = ChessNet().cuda().eval()
+    net_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.net_dtype]
+    net = InferenceNet(base, dtype=net_dtype)
     out = {"workload": f"selfplay_{args.games}x{args.sims}sims" + (f"_slots{args.slots}" if args.slots > 1 else ""),
-           "net": "ChessNet 20-block ResNet, random init (torch.manual_seed(0)), bf16 channels-last, HIP-graph replay"}
+           "net": f"ChessNet 20-block ResNet, random init (torch.manual_seed(0)), {args.net_dtype} channels-last, HIP-graph replay"}
+    if rank == 0:
+        # leaf-evaluator latency of the two 16-bit engines, interleaved (fp16: three more mantissa bits, same MFMA rate;
+        # parity of both against the reference's fp32 outputs: tests/test_net.py::test_inference_net_wide_parity)
+        other = InferenceNet(base, dtype=torch.float16 if net_dtype == torch.bfloat16 else torch.bfloat16)
+        x = (torch.rand((args.games * args.slots, 12, 12, 56), device="cuda") < 0.1)
+        xs = {id(net): x.to(net_dtype), id(other): x.to(other.dtype)}
+        for e in (net, other):
+            e(xs[id(e)])
+        torch.cuda.synchronize()
+        lat = {id(net): [], id(other): []}
+        for _ in range(6):
+            for e in (net, other):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    e(xs[id(e)])
+                e1.record()
+                torch.cuda.synchronize()
+                lat[id(e)].append(e0.elapsed_time(e1) / 5)
+        med = lambda v: sorted(v)[len(v) // 2]
+        out["leaf_forward_ms"] = {"leaves": args.games * args.slots,
+                                  str(net.dtype).replace("torch.", ""): round(med(lat[id(net)]), 4),
+                                  str(other.dtype).replace("torch.", ""): round(med(lat[id(other)]), 4)}
+        del other, xs, x
 
     if args.whole_games:
         lo = rank * args.games                              # global game ids: rank r plays games r*G .. (r+1)*G - 1
@@ -232,7 +269,7 @@ def selfplay_worker_measure(args, local_rank):
     try:
         w = SelfPlayWorker(total_games=args.games, games_per_gpu=args.games, sims=args.sims, gpus=[local_rank], seed=1234,
                            slots=args.slots, datapath=d, games_per_file=256, report_every=0, row_format="compact",
-                           log=lambda *_: None, warmup=True)
+                           log=lambda *_: None, warmup=True, net_dtype=args.net_dtype)
         t0 = time.time()
         res = w.start(timeout_s=900)
         t1 = time.time()
@@ -262,20 +299,33 @@ def training_measure(steps, batch=512):
     pi = torch.softmax(torch.randn((batch, 1584), device="cuda", generator=g), 1)
     z = torch.sign(torch.randn((batch,), device="cuda", generator=g))
     torch.manual_seed(0)
-    tr = Trainer(ChessNet().cuda(), ddp=False)
+    tr = Trainer(ChessNet().cuda(), ddp=False, freeze_gc=True)
     for _ in range(5):                          # the libraries' first-call searches (stem / head convolutions) end here
         tr.step(x, pi, z)
     torch.cuda.synchronize()
-    per_step = []
-    for _ in range(steps):
+    import gc
+    per_step, notes = [], []
+    gc_runs = [0]
+    def _gc_cb(phase, info):
+        if phase == "stop":
+            gc_runs[0] += 1
+    gc.callbacks.append(_gc_cb)
+    for i in range(steps):
+        s0, g0 = torch.cuda.memory_stats(), gc_runs[0]
         t0 = time.perf_counter()
         loss = tr.step(x, pi, z)                # (returns the loss as a float: one synchronise per step, like the reference's loop)
         per_step.append(time.perf_counter() - t0)
-    el = sorted(per_step)[len(per_step) // 2]   # median: a single allocator / garbage-collection hiccup is not the step
+        s1 = torch.cuda.memory_stats()
+        notes.append({"ms": round(per_step[-1] * 1e3, 2), "device_mallocs": s1["num_device_alloc"] - s0["num_device_alloc"],
+                      "gc_runs": gc_runs[0] - g0})
+    gc.callbacks.remove(_gc_cb)
+    # headline = the MEAN (what a training run pays).  Round 2's 106 ms outlier was a full CPython garbage collection
+    # landing in a step (profiles/r03_training_step.md); Trainer(freeze_gc=True) keeps those passes short
+    el = sum(per_step) / len(per_step)
     return {"workload": f"train_step_batch{batch}", "ms_per_step": round(el * 1e3, 2), "positions_per_s": round(batch / el, 1),
-            "ms_per_step_mean": round(sum(per_step) / len(per_step) * 1e3, 2), "ms_per_step_max": round(max(per_step) * 1e3, 2),
+            "ms_per_step_median": round(sorted(per_step)[len(per_step) // 2] * 1e3, 2), "ms_per_step_max": round(max(per_step) * 1e3, 2),
             "TFLOPs_fwd_bwd_as_3x_fwd": round(3 * GFLOP_PER_LEAF * batch / el / 1e3, 1), "dtype": "bf16 (fp32 master weights)",
-            "fused_hip_kernels": bool(tr.fused), "loss": round(float(loss), 4)}
+            "fused_hip_kernels": bool(tr.fused), "loss": round(float(loss), 4), "per_step": notes}
 
 
 def selfplay_cpu_baseline(sims, budget_s=10.0):
@@ -431,6 +481,7 @@ def main():
                     "concurrent launches stretch the per-kernel durations rocprof reports)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
                     "the multi-rank path on a single GPU")
+    ap.add_argument("--net-dtype", default="bf16", choices=["bf16", "fp16"], help="leaf-evaluator precision of the self-play legs")
     ap.add_argument("--no-records", dest="records", action="store_false", help="skip the records-on whole-game self-play leg")
     ap.add_argument("--no-worker", dest="worker", action="store_false", help="skip the SelfPlayWorker (spawned producer) leg")
     ap.add_argument("--encode-boards", type=int, default=65536, help="boards per launch of the planes-writer side measurement (0 = skip)")
@@ -550,6 +601,7 @@ def main():
                       "ms_per_step": round(el * 1e3 / args.steps, 6)}
 
     # side measurement: the same kernel on a batch large enough to fill all 256 CUs
+    ctr = movegen_counters()
     sat = None
     if rank == 0 and args.sat_boards > n:
         reps = args.sat_boards // n
@@ -571,10 +623,10 @@ def main():
         sat = {"boards_per_launch": nb, "ms_per_launch": round(ms, 4), "Mboards_per_s": round(nb / ms / 1e3, 2),
                "achieved_GBs": round(nb * ALGO_BYTES_PER_BOARD / ms / 1e6, 2),
                "frac_of_hbm_peak": round(nb * ALGO_BYTES_PER_BOARD / ms / 1e6 / HBM_PEAK_GBS, 5),
-               "valu_issue_roof": {"valu_wave_instr_per_board": MOVEGEN_VALU_PER_BOARD,
-                                   "peak_Mboards_per_s": round(VALU_ISSUE_PEAK_MBOARDS, 1),
-                                   "frac": round(nb / ms / 1e3 / VALU_ISSUE_PEAK_MBOARDS, 4),
-                                   "source": "profiles/r01_movegen_pmc_valu.md"}}
+               "valu_issue_roof": None if ctr is None else {
+                   "valu_wave_instr_per_board": round(ctr["valu_per_board"], 1),
+                   "peak_Mboards_per_s": round(ctr["valu_issue_peak_mboards"], 1),
+                   "frac": round(nb / ms / 1e3 / ctr["valu_issue_peak_mboards"], 4), "source": ctr["file"]}}
         del big, bm, bc
 
     # side measurement: the boundary handing over HOST buffers -- pinned boards in, pinned mask + count out, per step
@@ -655,11 +707,13 @@ def main():
             "config": {"workload": f"movegen_{n}", "boards_per_step_per_gpu": n, "mean_legal_moves": round(mean_legal, 2),
                        "corpus": "GPU random playouts, every ply sampled, seed 1000+rank", "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": MOVEGEN_TRAFFIC_BYTES_PER_BOARD * n,
-                         "traffic_source": MOVEGEN_TRAFFIC_SOURCE,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "traffic": None if ctr is None else int(round(ctr["traffic_bytes_per_board"] * n)),
+                         "traffic_source": None if ctr is None else f"{ctr['file']}: {ctr['source']} (separate rocprofv3 --pmc "
+                                           "passes of this command, gfx950 FETCH_SIZE correction applied; not measurable in-run)",
                          "kernel": "hive_piece_kernel<false>", "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_BOARD,
-                         "note": "VALU-issue bound (489 wave-instructions per board), not HBM bound: see saturated.valu_issue_roof; "
+                         "note": "VALU-issue bound (~489 wave-instructions per board), not HBM bound: see saturated.valu_issue_roof; "
                                  "4096 boards = 256 workgroups x 11 waves = one workgroup per CU; the 256 KB corpus is re-read "
                                  "every step, so the read side is served by L2 / Infinity Cache and the HBM label is nominal"},
             "movegen_with_sorted_id_list": with_list,

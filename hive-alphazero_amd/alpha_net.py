@@ -320,7 +320,12 @@ class Trainer:
     overlapped with backward by DDP); self-play itself never needs a collective.  `fused` (default: on for bf16 on a
     GPU) routes the tower's BatchNorm + skip + ReLU through the HIP kernels of csrc/hive_train.hip (FusedTrainNet)."""
 
-    def __init__(self, net, lr=0.001, autocast_dtype=torch.bfloat16, ddp=None, fused=None):
+    def __init__(self, net, lr=0.001, autocast_dtype=torch.bfloat16, ddp=None, fused=None, freeze_gc=False):
+        """freeze_gc: move everything allocated so far (torch, numpy, the model) into the garbage collector's permanent
+        generation (gc.freeze()).  A 16 ms step is short enough to notice CPython's full collections: in a process with
+        torch loaded one of them walks ~10^6 live objects and takes 80-110 ms, about once every few dozen steps
+        (profiles/r03_training_step.md: the step it lands in reads 95-126 ms).  Frozen, those passes only walk what was
+        allocated since."""
         import torch.distributed as dist
         self.device = next(net.parameters()).device
         self.net = net.to(memory_format=torch.channels_last)
@@ -336,6 +341,10 @@ class Trainer:
         self.criterion = AlphaLoss()
         self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr)
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=[100, 200, 300, 400], gamma=0.2)
+        if freeze_gc:
+            import gc
+            gc.collect()
+            gc.freeze()
 
     def loss(self, state_nchw, policy, value):
         x = state_nchw.to(self.device).float().contiguous(memory_format=torch.channels_last)

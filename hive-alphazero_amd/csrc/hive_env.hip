@@ -695,7 +695,7 @@ template <> struct PlaneVal<bf16_tag> {
     static __device__ __forceinline__ uint32_t of(unsigned v) { return __float_as_uint((float)v) >> 16; }   // v <= 255: exact
 };
 
-constexpr long long kExpandMaxBlocks = 256 * 16;      // 16 workgroups of 4 waves per CU keep every CU's store queue full
+constexpr long long kExpandMaxBlocks = 256 * 8;       // all resident at once: 8 workgroups of 4 waves per CU
 
 // Packed features (56 bits per cell) + history boards + turn -> the plane tensor (GamePlay.encode_board's output,
 // env_hive.py:320-447); pure streaming-store kernel.  A workgroup takes whole boards (grid-stride).  Per board: 144
@@ -747,7 +747,9 @@ hive_expand_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__re
             }
             full[buf][tid] = w;
         }
-        __syncthreads();       // (the other buffer is rewritten only after the NEXT barrier: no second one needed)
+        // (the other buffer is rewritten only after the NEXT barrier: no second one needed; a raw barrier behind an
+        // LDS-only wait, because __syncthreads() would also wait for the previous board's stores to be acknowledged)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (tid < kItems / 4) {
             HIVE_UNROLL for (int j = 0; j < 4; ++j) {
                 const int e0 = (tid + j * (kItems / 4)) * 8;

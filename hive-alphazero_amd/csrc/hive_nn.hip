@@ -126,12 +126,12 @@ __device__ __forceinline__ void conv_taps(const unsigned char *lds, unsigned zof
                 wp += KSTEP * sizeof(T);
                 const int ahead = tap * KC + kc + AD - 9 * KC;      // >= 0: that k-step belongs to the next convolution
                 const char *wl = ahead >= 0 ? wtail + (size_t)ahead * KSTEP * sizeof(T) : wp;
-#ifndef HIVE_ABL_NOA                    /* timing-only ablation: no weight stream */
+#if defined(HIVE_ABL_NOA)               /* timing-only ablation (profiles/r03_net_tower.md): no weight stream */
+                if (wl == nullptr) A[(q + AD) % RING][0] = *reinterpret_cast<const v8 *>(wl + wlane);
+#else
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     A[(q + AD) % RING][mt] = *reinterpret_cast<const v8 *>(wl + wlane + mt * 1024);
-#else
-                if (wl == nullptr) A[(q + AD) % RING][0] = *reinterpret_cast<const v8 *>(wl + wlane);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 v8 Bf[NTL];
@@ -139,7 +139,7 @@ __device__ __forceinline__ void conv_taps(const unsigned char *lds, unsigned zof
                 for (int d = 0; d < D; ++d) Bf[d] = Bn[d];
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt) {
-#ifdef HIVE_ABL_NOB                     /* timing-only ablation: no LDS fragment reads */
+#ifdef HIVE_ABL_NOB                     /* timing-only ablation (profiles/r03_net_tower.md): no LDS fragment reads */
                     if (nt + D < NTL) {
                         Bf[nt + D] = Bf[nt];
                     } else if (boff[0] == 0xffffffffu) {
@@ -431,10 +431,6 @@ tower_kernel(const typename E::T *__restrict__ X, const typename E::T *__restric
         for (int mt = 0; mt < MT; ++mt)
             A[j][mt] = *reinterpret_cast<const v8 *>(reinterpret_cast<const char *>(W + (size_t)j * (16 * 512)) + wlane + mt * 1024);
     __syncthreads();
-#ifdef HIVE_TOWER_STAGGER                  /* experiment: start every other workgroup late (bit HIVE_TOWER_STAGGER_BIT of its id) */
-    if ((blockIdx.x >> HIVE_TOWER_STAGGER_BIT) & 1)
-        for (int i = 0; i < HIVE_TOWER_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
 
 #pragma unroll 1
     for (int blk = 0; blk < nblocks; ++blk) {

@@ -522,3 +522,115 @@ def test_compact_games_widen_to_trainer_tensors_on_the_gpu():
         assert np.array_equal(hwc.float().cpu().numpy(), states)
         assert np.array_equal(chw.float().cpu().numpy(), states.transpose(0, 3, 1, 2))
         assert np.array_equal(pol.cpu().numpy(), policies) and np.allclose(val.cpu().numpy(), values, atol=1e-6)
+
+
+def test_finished_selfplay_games_replay_through_the_oracle(bf16_net):
+    """The whole producer chain -- noisy search, move resampling on turns 1..6, env step, per-ply records, scoring -- for
+    128 games played to their end (8 simulations per move, bf16 network), judged by the CPU oracle instead of by the GPU's
+    own legal mask: the moves are recovered from consecutive recorded planes on oracle_py.OracleGame (the action after
+    which the next recorded planes appear), so every played move is in the ORACLE's legal set, every recorded plane
+    tensor equals the oracle's encode_board of that position, a side with an empty recorded policy really had no move,
+    the recorded result is the oracle's winner (draw / length cap -> 0 -> value -1 for both sides), and the rows'
+    value and [game_len, counter] fields are consistent (woker/self_play.py:116-193)."""
+    from oracle import oracle_py as O
+    from hive_alphazero_amd import mcts, records
+    G, sims = 128, 8
+    sp = mcts.SelfPlay(G, sims, bf16_net, seed=21, keep_records=True, game_ids=range(G), max_finished_kept=2 * G)
+    games = []
+    for _ in range(60):
+        sp.play_ply()
+        games += sp.drain_finished()
+        if sp.running() == 0:
+            break
+    assert sp.running() == 0 and len(games) == G and sp.dropped_games == 0 and sp.unrecorded_games == 0
+    assert sp.env.illegal_count() == 0
+    assert sorted(e[2] for e in games) == list(range(G))
+    decisive = plies_checked = passes = 0
+    for value_white, plies, gid in games:
+        g = O.OracleGame()
+        planes = [records.unpack_features(w, t, records.history_planes(hw, hl)) for (w, hw, hl, t, pol, mover) in plies]
+        for k, (w, hw, hl, t, pol, mover) in enumerate(plies):
+            assert g.turn == t and mover == (0 if t % 2 == 1 else 1), (gid, k)
+            assert np.array_equal(planes[k], g.encode_board().astype(np.float64)), (gid, k)      # recorded == oracle planes
+            legal = g.actions()
+            support = np.flatnonzero(pol).tolist()
+            assert set(support) <= set(legal), (gid, k)
+            plies_checked += 1
+            if not legal:
+                assert pol.sum() == 0
+                g.move(-1)
+                passes += 1
+                continue
+            assert abs(pol.sum() - 1.0) < 1e-4
+            found = None
+            if k + 1 < len(plies):
+                for a in legal:                    # (not only the policy's support: turns 1..6 resample with uniform noise)
+                    nxt = g.copy()
+                    nxt.move(a)
+                    if nxt.turn == plies[k + 1][3] and np.array_equal(nxt.encode_board().astype(np.float64), planes[k + 1]):
+                        found = a
+                        break
+            else:                                  # the last ply: some legal move ends the game the way it was scored
+                for a in legal:
+                    nxt = g.copy()
+                    nxt.move(a)
+                    over, w_ = nxt.game_is_over()
+                    vw = 1 if w_ == 1 else (-1 if w_ == 2 else 0)
+                    if (over and vw == value_white) or (not over and nxt.turn >= 55 and value_white == 0):
+                        found = a
+                        break
+            assert found is not None, (gid, k, t)
+            g.move(found)
+        over, w_ = g.game_is_over()
+        assert over or g.turn >= 55, gid
+        assert value_white == (1 if w_ == 1 else (-1 if w_ == 2 else 0)) or (not over and value_white == 0), gid
+        decisive += int(value_white != 0)
+        rows = records.rows_from_game((value_white, plies, gid))
+        n_side = [sum(1 for p in plies if p[5] == s) for s in (0, 1)]
+        seen = [0, 0]
+        for (state, policy, value, lens), p in zip(rows, plies):
+            side = p[5]
+            seen[side] += 1
+            assert lens == [n_side[side], seen[side]]
+            assert value == (-1 if value_white == 0 else (value_white if side == 0 else -value_white))
+    print(f"oracle replay: {G} games, {plies_checked} plies, {passes} passes, {decisive} decisive games")
+    assert plies_checked > 40 * G
+    sp.close()
+
+
+def test_config3_shards_of_8192_game_ids_rehearsed_on_one_gpu(bf16_net):
+    """BASELINE configs[3] (8192 concurrent games sharded over 8 GPUs, 1024 each) rehearsed on ONE GPU: the eight ranks'
+    shards of the global game ids 0..8191 (dist.game_id_stream) are disjoint and complete, and each shard is played one
+    after another for two plies on engines of 1024 games; shard 5's games are then played again inside a differently
+    shaped engine (slots 100..1123 of a 1280-game engine whose other slots hold other ids): same moves, same visit
+    policies -- a game's record does not depend on the rank, the batch position or the batch size it ran in."""
+    from hive_alphazero_amd import dist as hd
+    from hive_alphazero_amd import mcts
+    world, total, per = 8, 8192, 1024
+    shards = [list(hd.game_id_stream(r, world, total)) for r in range(world)]
+    assert all(len(s) == per for s in shards)
+    assert sorted(i for s in shards for i in s) == list(range(total))
+    assert all(s == list(range(r * per, (r + 1) * per)) for r, s in enumerate(shards))
+    sims, plies = 50, 2
+    played = {}
+    for r in range(world):
+        sp = mcts.SelfPlay(per, sims, bf16_net, seed=99, keep_records=False, game_ids=iter(shards[r]))
+        assert sp.game_id.cpu().tolist() == shards[r]
+        moves = []
+        for _ in range(plies):
+            sp.play_ply()
+            moves.append((sp.search.action.cpu().clone(), sp.search.policy.cpu().clone()))
+        assert sp.env.illegal_count() == 0
+        played[r] = moves
+        sp.close()
+    # the same ids in another batch shape
+    ids = list(range(90000, 90100)) + shards[5] + list(range(91000, 91156))
+    sp = mcts.SelfPlay(1280, sims, bf16_net, seed=99, keep_records=False, game_ids=iter(ids))
+    for k in range(plies):
+        sp.play_ply()
+        a, p = sp.search.action.cpu()[100:1124], sp.search.policy.cpu()[100:1124]
+        assert torch.equal(a, played[5][k][0])
+        assert float((p - played[5][k][1]).abs().max()) < 1e-6
+    sp.close()
+    # games of different shards differ (the noise is keyed on the game id, not on the slot)
+    assert not torch.equal(played[0][1][0], played[1][1][0])

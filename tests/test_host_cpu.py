@@ -317,3 +317,35 @@ def test_compact_game_files_expand_to_the_reference_rows(tmp_path):
     assert len(via_json) == len(states) == 20
     for (s, p, v), s2, p2, v2 in zip(via_json, states, policies, values):
         assert np.array_equal(s.astype(np.float32), s2) and np.array_equal(p, p2) and abs(v - v2) < 1e-6
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself(monkeypatch):
+    """bench.py --gpus N (driver contract): without RANK in the environment the process starts N ranks under
+    torch.distributed.run as a CHILD (before anything touches the GPU), forwards its argv, relays the child's exit code;
+    with WORLD_SIZE set and different from --gpus it refuses to run.  (woker/self_play.py:54-56 is the reference's pool.)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import importlib
+    bench = importlib.import_module("bench")
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 7)
+    rc = bench.relaunch_under_torchrun(["--gpus", "4", "--steps", "5", "--dist-backend", "gloo"], 4)
+    (cmd, env), = calls
+    assert rc == 7 and cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "5", "--dist-backend", "gloo"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.undo()
+    # a rank count that contradicts the launcher's is refused before any import of torch
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    # no launcher on the command line: two ranks come up under torchrun (here they stop at "needs a GPU": this container has none)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+    else:
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert r.returncode == 0 and line["n_gpus"] == 2
