@@ -202,6 +202,9 @@ class SelfPlay:
         self.max_finished_kept = max_finished_kept
         self.dropped_games = self.unrecorded_games = 0
         self.report_every, self._log_fn, self._reported = report_every, log, 0
+        # per-ply record copies leave on a side stream into pinned host buffers while the next search runs
+        self._copy_stream = torch.cuda.Stream(self.device) if keep_records else None
+        self._copy_done = None       # event of the newest record copy (entries of self._log are valid once it has passed)
 
     def stagger(self, seed=0):
         """Spread the games over plies 0..53 with uniformly random legal moves so that a timed window
@@ -269,9 +272,15 @@ class SelfPlay:
         """Mean number of plies of the finished games (final turn number - 1)."""
         return (sum(self.finished_turns) / len(self.finished_turns) - 1.0) if self.finished_turns else 0.0
 
+    def _log_ready(self):
+        """Wait for the newest per-ply record copy (issued a whole search ago: it has long finished)."""
+        if self._copy_done is not None:
+            self._copy_done.synchronize()
+
     def _close_games(self, slots, winner, ids):
         """self_play.py:165-191: value_white = +1 / -1 / 0; a draw or the length cap scores -1 for both."""
         import warnings
+        self._log_ready()
         for s in slots:
             start, self._start_ply[s] = self._start_ply[s], self.plies
             unlogged, self._unlogged[s] = self._unlogged[s], False
@@ -306,6 +315,7 @@ class SelfPlay:
         return (entry["feat"][g].copy(), entry["hist"][g, persp].copy(), hlen, turn, entry["policy"][g].copy(), persp)
 
     def last_ply_record(self, g):
+        self._log_ready()
         return self.ply_record(self._log[-1], g) if self._log and self._log[-1]["moved"][g] else None
 
     @staticmethod
@@ -324,22 +334,41 @@ class SelfPlay:
         through the record path; -2 = keep the search's choice)."""
         nd = self._retire_finished()
         boards, hist = self.env.export_state()
+        if self._copy_done is not None:
+            # the search's policy buffer is rewritten at the end of this search: it waits for the previous ply's record copy
+            torch.cuda.current_stream(self.device).wait_event(self._copy_done)
         action, policy, sum_n = self.search.search(boards, hist, active=self.active, selfplay=True,
                                                    keep_root_planes=self.keep_records)
         if self.keep_records:
             mover = (1 - (boards[:, 33] & 1)).to(torch.int8)
-            self.records.append((self.search.root_planes.view(self.games, 144), policy.clone(), mover, self.game_id.clone()))
+            feat = self.search.root_planes.view(self.games, 144)
+            self.records.append((feat, policy.clone(), mover, self.game_id.clone()))
             if len(self.records) > 8:
                 self.records.pop(0)
-            # host copies of this ply for the per-game records (8 MB per ply at 1024 games; whole arrays, the
-            # per-game rows are cut out only when a game ends)
+            # host copies of this ply for the per-game records (8 MB per ply at 1024 games; whole arrays, the per-game
+            # rows are cut out only when a game ends).  They leave asynchronously: a side stream copies into pinned
+            # buffers while the main stream goes on with the env step and the next search (self_play.py:159-160 appends a
+            # row per ply in the game loop itself; here that costs the engine nothing but the PCIe transfer)
+            moved = action != -2
+            src = {"feat": feat, "policy": policy, "boards": boards, "hist": hist, "moved": moved}
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in src.items()}
+            with torch.cuda.stream(self._copy_stream):
+                self._copy_stream.wait_event(ready)
+                for k, v in src.items():
+                    host[k].copy_(v, non_blocking=True)
+                    v.record_stream(self._copy_stream)
+                self._copy_done = torch.cuda.Event()
+                self._copy_done.record(self._copy_stream)
             self._log.append({
                 "ply": self.plies,
-                "feat": self.search.root_planes.view(self.games, 144).cpu().numpy().view("uint64"),
-                "policy": policy.cpu().numpy(),
-                "boards": boards.cpu().numpy(),
-                "hist": hist.cpu().numpy().view("uint32").reshape(self.games, 2, 4, 2, 6),
-                "moved": (action != -2).cpu().numpy(),
+                "feat": host["feat"].numpy().view("uint64"),
+                "policy": host["policy"].numpy(),
+                "boards": host["boards"].numpy(),
+                "hist": host["hist"].numpy().view("uint32").reshape(self.games, 2, 4, 2, 6),
+                "moved": host["moved"].numpy(),
+                "_pinned": host,                 # keeps the pinned tensors (the arrays above are views) alive
             })
             oldest = min(self._start_ply)
             while self._log and self._log[0]["ply"] < oldest:
