@@ -695,14 +695,14 @@ template <> struct PlaneVal<bf16_tag> {
     static __device__ __forceinline__ uint32_t of(unsigned v) { return __float_as_uint((float)v) >> 16; }   // v <= 255: exact
 };
 
+constexpr int kExpandAhead = 4;                        // boards whose inputs are in flight per workgroup
 constexpr long long kExpandMaxBlocks = 256 * 8;       // all resident at once: 8 workgroups of 4 waves per CU
 
 // Packed features (56 bits per cell) + history boards + turn -> the plane tensor (GamePlay.encode_board's output,
 // env_hive.py:320-447); pure streaming-store kernel.  A workgroup takes whole boards (grid-stride).  Per board: 144
 // threads complete the cells' 56-bit words in LDS (packed features | the eight history bits of planes 36..43, read from
-// the history bitboards: env_hive.py:431-434) -- one barrier, double-buffered --, then thread t < 252 writes the four
-// 16-byte (f16 / bf16; 32-byte f32) items t, t + 252, t + 504, t + 756 of the board: consecutive lanes write consecutive
-// pieces, nothing is divided by a runtime value, and no global load sits between a thread and its stores.
+// the history bitboards: env_hive.py:431-434) -- one barrier, double-buffered --, then thread t writes the 16-byte (f16 / bf16; 32-byte f32)
+// items t, t + 256, t + 512, t + 768 (< 1008) of the board: consecutive lanes write consecutive, line-aligned pieces, nothing is divided by a runtime value, and no global load sits between a thread and its stores.
 // (One workgroup per 256 items with per-item history loads ran at 2.0 TB/s of 6.9 the card stores: profiles/r03_encode.md.)
 template <int DT, int LAYOUT>
 __global__ void __launch_bounds__(256)
@@ -715,21 +715,27 @@ hive_expand_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__re
     const uint32_t one = PlaneVal<V>::one();
     const int tid = threadIdx.x;
     int buf = 0;
-    // the next board's record bytes and packed word are requested one board ahead, so that their latency runs under this
-    // board's stores
-    uint32_t meta_n = 0u;
-    unsigned long long word_n = 0ull;
-    if ((long long)blockIdx.x < n) {
-        meta_n = reinterpret_cast<const uint32_t *>(&boards[blockIdx.x])[8];    // bytes 32..35
-        if (tid < kCells) word_n = feat[(long long)blockIdx.x * kCells + tid];
+    // the record bytes and packed words of the next kExpandAhead boards are in flight: loads and stores retire through ONE
+    // in-order counter, so a load requested d boards ahead only waits for stores that are d boards old
+    uint32_t meta_q[kExpandAhead];
+    unsigned long long word_q[kExpandAhead];
+    HIVE_UNROLL for (int d = 0; d < kExpandAhead; ++d) {
+        const long long bq = (long long)blockIdx.x + (long long)d * gridDim.x;
+        meta_q[d] = 0u;
+        word_q[d] = 0ull;
+        if (bq < n) {
+            meta_q[d] = reinterpret_cast<const uint32_t *>(&boards[bq])[8];    // bytes 32..35
+            if (tid < kCells) word_q[d] = feat[bq * kCells + tid];
+        }
     }
     for (long long b = blockIdx.x; b < n; b += gridDim.x, buf ^= 1) {
-        const uint32_t meta = meta_n;
-        unsigned long long w = word_n;
-        const long long bn = b + gridDim.x;
+        const uint32_t meta = meta_q[0];
+        unsigned long long w = word_q[0];
+        HIVE_UNROLL for (int d = 0; d + 1 < kExpandAhead; ++d) { meta_q[d] = meta_q[d + 1]; word_q[d] = word_q[d + 1]; }
+        const long long bn = b + (long long)kExpandAhead * gridDim.x;
         if (bn < n) {
-            meta_n = reinterpret_cast<const uint32_t *>(&boards[bn])[8];
-            if (tid < kCells) word_n = feat[bn * kCells + tid];
+            meta_q[kExpandAhead - 1] = reinterpret_cast<const uint32_t *>(&boards[bn])[8];
+            if (tid < kCells) word_q[kExpandAhead - 1] = feat[bn * kCells + tid];
         }
         const unsigned turn = (meta >> 8) & 0xFFu, hl = meta >> 24;
         const int persp = (turn & 1u) ? 0 : 1;
@@ -750,9 +756,11 @@ hive_expand_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__re
         // (the other buffer is rewritten only after the NEXT barrier: no second one needed; a raw barrier behind an
         // LDS-only wait, because __syncthreads() would also wait for the previous board's stores to be acknowledged)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (tid < kItems / 4) {
+        {
+            // items tid, tid + 256, tid + 512, tid + 768 (< 1008): every wave's store is one 128-byte-aligned KiB
             HIVE_UNROLL for (int j = 0; j < 4; ++j) {
-                const int e0 = (tid + j * (kItems / 4)) * 8;
+                if (j == 3 && tid >= kItems - 768) break;
+                const int e0 = (tid + j * 256) * 8;
                 uint32_t v[8];
                 if (LAYOUT == HIVE_HWC) {
                     const int cell = e0 / HIVE_PLANES, p0 = e0 - cell * HIVE_PLANES;

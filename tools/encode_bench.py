@@ -4,6 +4,8 @@ Usage: encode_bench.py [boards]   (run under rocprofv3 --pmc FETCH_SIZE / WRITE_
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hive_alphazero_amd as h
+from hive_alphazero_amd import _lib as _l
+_l.SO_PATH = os.environ.get('HIVE_SO', _l.SO_PATH)      # a variant build of the whole library (A/B of one kernel)
 from hive_alphazero_amd import playout
 from hive_alphazero_amd._lib import BF16, F32, HWC, CHW
 L = h.load()
