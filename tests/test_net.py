@@ -679,3 +679,34 @@ def test_reduced_precision_search_agrees_with_fp32_search():
         dpi = np.abs(res[name][1][live] - res["fp32"][1][live])
         print(f"search {name} vs fp32: same move {agree:.3f}, max |d pi| {dpi.max():.3f}, mean of per-position max {dpi.max(1).mean():.4f}")
         assert agree >= min_agree and dpi.max(1).mean() <= max_dpi, (name, agree, float(dpi.max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_inference_net_tower_forms_give_the_same_bits(dtype):
+    """InferenceNet(tower=1|2|3) (the whole residual tower in one hive_nn_tower launch, three workgroup forms) against the
+    default launch-per-block chain: identical policy and value outputs, eagerly and through the captured HIP graph, and
+    after refresh() with new weights (the one weight buffer the tower reads and the per-block views share storage)."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    torch.manual_seed(1)
+    net = ChessNet().cuda().eval()
+    x = (torch.rand((37, 12, 12, 56), device="cuda") < 0.08).to(dtype)
+    x[..., 31] = 17.0
+    ref = InferenceNet(net, dtype=dtype, tower=0)
+    p0, v0 = ref(x)
+    engines = {t: InferenceNet(net, dtype=dtype, tower=t) for t in (1, 2, 3)}
+    for t, inf in engines.items():
+        p, v = inf(x)
+        assert torch.equal(p, p0) and torch.equal(v, v0), t
+        p, v = inf(x)                                  # graph replay
+        assert torch.equal(p, p0) and torch.equal(v, v0), t
+    torch.manual_seed(2)
+    net2 = ChessNet().cuda().eval()
+    ref.refresh(net2)
+    p1, v1 = ref(x)
+    assert not torch.equal(p1, p0)
+    for t, inf in engines.items():
+        inf.refresh(net2)
+        p, v = inf(x)
+        assert torch.equal(p, p1) and torch.equal(v, v1), t
