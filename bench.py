@@ -435,12 +435,12 @@ def encode_measure(L, n=65536, steps=20):
         key = "encode" if name.startswith("encode") else "planes_writer"
         out[key] = {"kernel": name, "ms_per_launch": round(ms, 4), "Mboards_per_s": round(n / ms / 1e3, 2)}
         if key == "planes_writer":
-            alg = n * (ENCODE_BYTES_PER_BOARD + 1152 + 384 + 64)
+            alg = n * (ENCODE_BYTES_PER_BOARD + 1152 + 64)
             out[key]["roofline"] = {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
                                     "algorithmic_bytes_per_launch": alg,
-                                    "note": "16,128 B written + 1,600 B read per board; PMC FETCH/WRITE_SIZE passes: "
-                                            "profiles/r03_encode_pmc.md"}
+                                    "note": "16,128 B written + 1,216 B read per board (history empty in this corpus); PMC "
+                                            "FETCH/WRITE_SIZE passes: profiles/r03_encode_pmc.md"}
     return out
 
 

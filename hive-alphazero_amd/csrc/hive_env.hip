@@ -695,6 +695,16 @@ template <> struct PlaneVal<bf16_tag> {
     static __device__ __forceinline__ uint32_t of(unsigned v) { return __float_as_uint((float)v) >> 16; }   // v <= 255: exact
 };
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// NT: streaming (nontemporal) stores for launches whose output is far larger than the caches -- 5.3 instead of 4.2 TB/s at
+// 65,536 boards (1 GB of planes); leaf batches of a search (<= 4096 boards, read back at once by the network) keep plain stores
+template <bool NT>
+__device__ __forceinline__ void plane_store(u32x4 val, u32x4 *ptr)
+{
+    if (NT) __builtin_nontemporal_store(val, ptr);
+    else *ptr = val;
+}
+constexpr int kExpandStreamBoards = 8192;              // from this many boards per launch (127 MB of bf16 planes) on: NT stores
 constexpr int kExpandAhead = 4;                        // boards whose inputs are in flight per workgroup
 constexpr long long kExpandMaxBlocks = 256 * 8;       // all resident at once: 8 workgroups of 4 waves per CU
 
@@ -704,7 +714,7 @@ constexpr long long kExpandMaxBlocks = 256 * 8;       // all resident at once: 8
 // the history bitboards: env_hive.py:431-434) -- one barrier, double-buffered --, then thread t writes the 16-byte (f16 / bf16; 32-byte f32)
 // items t, t + 256, t + 512, t + 768 (< 1008) of the board: consecutive lanes write consecutive, line-aligned pieces, nothing is divided by a runtime value, and no global load sits between a thread and its stores.
 // (One workgroup per 256 items with per-item history loads ran at 2.0 TB/s of 6.9 the card stores: profiles/r03_encode.md.)
-template <int DT, int LAYOUT>
+template <int DT, int LAYOUT, bool NT>
 __global__ void __launch_bounds__(256)
 hive_expand_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restrict__ hist,
                    const unsigned long long *__restrict__ feat, int n, void *__restrict__ planes)
@@ -774,12 +784,12 @@ hive_expand_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__re
                 }
                 const long long eoff = b * (long long)(kCells * HIVE_PLANES) + e0;
                 if (DT == 0) {
-                    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<float *>(planes) + eoff);
-                    dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
-                    dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
+                    u32x4 *dst = reinterpret_cast<u32x4 *>(reinterpret_cast<float *>(planes) + eoff);
+                    plane_store<NT>(u32x4{v[0], v[1], v[2], v[3]}, dst);
+                    plane_store<NT>(u32x4{v[4], v[5], v[6], v[7]}, dst + 1);
                 } else {
-                    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(planes) + eoff);
-                    dst[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+                    u32x4 *dst = reinterpret_cast<u32x4 *>(reinterpret_cast<uint16_t *>(planes) + eoff);
+                    plane_store<NT>(u32x4{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)}, dst);
                 }
             }
         }
@@ -940,8 +950,12 @@ static int launch_encode(const HiveBoard *boards, const HiveHistory *hist, int n
     HIP_TRY(hipGetLastError());
     dim3 grid((unsigned)std::min<long long>(n, kExpandMaxBlocks));
 #define HIVE_EXP_CASE(DT, LY)                                                                                  \
-    if (dtype == DT && layout == LY)                                                                           \
-        hipLaunchKernelGGL((hive_expand_kernel<DT, LY>), grid, dim3(256), 0, stream, boards, hist, feat, n, planes);
+    if (dtype == DT && layout == LY) {                                                                         \
+        if (n >= kExpandStreamBoards)                                                                          \
+            hipLaunchKernelGGL((hive_expand_kernel<DT, LY, true>), grid, dim3(256), 0, stream, boards, hist, feat, n, planes); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((hive_expand_kernel<DT, LY, false>), grid, dim3(256), 0, stream, boards, hist, feat, n, planes); \
+    }
     HIVE_EXP_CASE(0, 0) HIVE_EXP_CASE(0, 1) HIVE_EXP_CASE(1, 0) HIVE_EXP_CASE(1, 1) HIVE_EXP_CASE(2, 0) HIVE_EXP_CASE(2, 1)
 #undef HIVE_EXP_CASE
     HIP_TRY(hipGetLastError());
@@ -970,8 +984,12 @@ int hive_expand_launch(const HiveBoard *boards, const HiveHistory *hist, const v
     dim3 grid((unsigned)std::min<long long>(n, kExpandMaxBlocks));
     const unsigned long long *feat = (const unsigned long long *)features;
 #define HIVE_EXP_CASE(DT, LY)                                                                                  \
-    if (dt == DT && ly == LY)                                                                                  \
-        hipLaunchKernelGGL((hive_expand_kernel<DT, LY>), grid, dim3(256), 0, (hipStream_t)stream, boards, hist, feat, n, planes);
+    if (dt == DT && ly == LY) {                                                                                \
+        if (n >= kExpandStreamBoards)                                                                          \
+            hipLaunchKernelGGL((hive_expand_kernel<DT, LY, true>), grid, dim3(256), 0, (hipStream_t)stream, boards, hist, feat, n, planes); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((hive_expand_kernel<DT, LY, false>), grid, dim3(256), 0, (hipStream_t)stream, boards, hist, feat, n, planes); \
+    }
     HIVE_EXP_CASE(0, 0) HIVE_EXP_CASE(0, 1) HIVE_EXP_CASE(1, 0) HIVE_EXP_CASE(1, 1) HIVE_EXP_CASE(2, 0) HIVE_EXP_CASE(2, 1)
 #undef HIVE_EXP_CASE
     HIP_TRY(hipGetLastError());

@@ -366,3 +366,34 @@ def test_abi_argument_errors(hv):
     pl = B.encode(torch.float32, "hwc")
     assert float(pl[..., 31].min()) == 1.0 and float(pl.sum()) == 2 * 144.0
     B.close()
+
+
+def test_planes_writer_streaming_launch_equals_small_launches(hv):
+    """hive_expand_kernel switches to streaming (nontemporal) stores from 8192 boards per launch on: a 8192 + 37 board encode
+    (f32 / bf16, HWC / CHW, history on) equals the same boards encoded in launches of 1000 (the plain-store instantiation)."""
+    h, batch, packing = hv
+    import ctypes
+    from hive_alphazero_amd import playout
+    from hive_alphazero_amd._lib import BF16, F32, HWC, CHW
+    L = h.load()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    n = 8192 + 37
+    base = playout.random_positions(4096, seed=9)
+    boards = torch.cat([base, base, base[:37]]).contiguous()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    hist = torch.randint(0, 256, (n, 384), dtype=torch.uint8, device="cuda", generator=g)
+    hist[:, 0::4] &= 0xFF; hist[:, 1::4] &= 0x0F; hist[:, 3::4] &= 0x0F            # 12-bit rows in 16-bit fields
+    boards[:, 35] = torch.randint(0, 5, (n,), dtype=torch.uint8, device="cuda", generator=g) * 17      # history lengths 0..4 / 0..4
+    ws = torch.empty((n * 144,), dtype=torch.int64, device="cuda")
+    for dt, tdt in ((BF16, torch.bfloat16), (F32, torch.float32)):
+        for ly, shape in ((HWC, (n, 12, 12, 56)), (CHW, (n, 56, 12, 12))):
+            big = torch.full(shape, float("nan"), dtype=tdt, device="cuda")
+            assert L.hive_encode_launch(P(boards), P(hist), n, P(big), dt, ly, P(ws), None) == 0
+            small = torch.full(shape, float("nan"), dtype=tdt, device="cuda")
+            for lo in range(0, n, 1000):
+                k = min(1000, n - lo)
+                assert L.hive_expand_launch(P(boards[lo:]), P(hist[lo:]), P(ws[lo * 144:]), k, P(small[lo:]), dt, ly, None) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(big.view(torch.int16 if tdt == torch.bfloat16 else torch.int32),
+                               small.view(torch.int16 if tdt == torch.bfloat16 else torch.int32)), (dt, ly)
+            assert bool(torch.isfinite(big.float()).all())

@@ -585,7 +585,9 @@ def _wide_metrics(p, v, p_ref, v_ref, legal):
         if len(lg) == 0:
             continue
         pr, pm = p_ref[b].astype(np.float64), p[b]
-        dlog = max(dlog, float(np.abs(np.log(pm[lg]) - np.log(pr[lg])).max()))
+        seen = lg[pr[lg] > 1e-30]                 # (peaked logits push a few legal moves below fp32's range: log 0 on both sides)
+        with np.errstate(divide="ignore"):
+            dlog = max(dlog, float(np.abs(np.log(pm[seen]) - np.log(pr[seen])).max()))
         kl = max(kl, float((pr * (np.log(pr + 1e-300) - np.log(pm + 1e-300))).sum()))
         order_r, order_m = lg[np.argsort(-pr[lg], kind="stable")], lg[np.argsort(-pm[lg], kind="stable")]
         top1 += int(order_r[0] == order_m[0])
