@@ -401,33 +401,46 @@ __device__ __forceinline__ void pin_phase(Smem<FULL> &sm, int wave, int lane)
 // cell test on a lane-distributed board (result replicated over the quad)
 __device__ __forceinline__ bool bb_test(BB x, unsigned cell) { return bb_any(bb_and(x, bb_bit(cell))); }
 
-// GamePlay.encode_action (env_hive.py:287-304) for one board, by one wave: {slot: destination board} (66 words in LDS)
-// -> ascending action ids.  Action id = cell * 11 + slot, i.e. the bit index of the 11 x 144 slot-major bit matrix
-// TRANSPOSED: (1) lane l of pass t (three passes cover the 144 cells) gathers the 11 slot bits of cell 64 t + l and ORs
-// them at bit cell * 11 of a 1584-bit id-ordered mask in LDS; (2) lane j then owns word j of that mask (50 words): a
-// ballot / v_mbcnt prefix over the words' popcounts gives each word its place in the list, its set bits are laid down
-// in an LDS row, and the row leaves as one coalesced 8-byte store per lane (-1 padded).
-__device__ __forceinline__ void build_id_list(const uint32_t *dest, uint32_t *idmask, int16_t *rowbuf, int16_t *out, int lane)
+// GamePlay.encode_action (env_hive.py:287-304): {slot: destination board} -> ascending action ids.  Action id =
+// cell * 11 + slot, i.e. the bit index of the 11 x 144 slot-major bit matrix TRANSPOSED into a 1584-bit id-ordered mask
+// (50 words in LDS).  Two steps:
+//   scatter   the set bits of destination words are ORed into the id-ordered mask (ds_or_b32).  In the fused movegen launch
+//             every (board, slot) quad does this for its own two words as soon as it has them -- spread over all eleven
+//             waves and, for ten of them, off the critical path; `transpose_dest_board` is the one-wave form for callers
+//             that only hold the 66-word destination image.
+//   emit      lane j owns word j of the mask: six ballots + v_mbcnt over the words' popcounts give every word its place in
+//             the list, its set bits are laid down in an LDS row, and the row leaves as one coalesced 8-byte store per
+//             lane (-1 padded).
+__device__ __forceinline__ void scatter_slot_bits(uint32_t *idmask, unsigned long long w, unsigned row0, unsigned slot)
 {
-    reinterpret_cast<unsigned long long *>(rowbuf)[lane] = 0xFFFFFFFFFFFFFFFFull;      // four -1 entries per lane
+    // w: four board rows of one slot's destination board (row r at bits 16 r .. 16 r + 11); row0 = the first of them
+    while (w) {
+        const unsigned bidx = (unsigned)__builtin_ctzll(w);
+        w &= w - 1ull;
+        const unsigned id = ((row0 + (bidx >> 4)) * 12u + (bidx & 15u)) * 11u + slot;
+        atomicOr(&idmask[id >> 5], 1u << (id & 31u));
+    }
+}
+
+__device__ __forceinline__ void transpose_dest_board(const uint32_t *dest, uint32_t *idmask, int lane)
+{
     if (lane < 52) idmask[lane] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // same-wave LDS traffic only: program order suffices
     __builtin_amdgcn_wave_barrier();
-    HIVE_UNROLL for (int t = 0; t < 3; ++t) {
-        const unsigned cell = 64u * (unsigned)t + (unsigned)lane;
-        if (cell < (unsigned)kCells) {
-            unsigned wi, bit, bits = 0u;
-            cell_word_bit(cell, wi, bit);
-            HIVE_UNROLL for (unsigned sl = 0; sl < 11u; ++sl) bits |= ((dest[sl * 6u + wi] >> bit) & 1u) << sl;
-            if (bits) {
-                const unsigned off = cell * 11u, w = off >> 5, sh = off & 31u;
-                atomicOr(&idmask[w], bits << sh);
-                if (sh > 21u) atomicOr(&idmask[w + 1u], bits >> (32u - sh));
-            }
-        }
+    // lane l < 33: slot l / 3, word pair (l % 3) of that slot's six words = four board rows
+    if (lane < 33) {
+        const unsigned slot = (unsigned)lane / 3u, pair = (unsigned)lane - slot * 3u;
+        const unsigned long long w = (unsigned long long)dest[slot * 6u + 2u * pair] |
+                                     ((unsigned long long)dest[slot * 6u + 2u * pair + 1u] << 32);
+        scatter_slot_bits(idmask, w, 4u * pair, slot);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void emit_id_list(const uint32_t *idmask, int16_t *rowbuf, int16_t *out, int lane)
+{
+    reinterpret_cast<unsigned long long *>(rowbuf)[lane] = 0xFFFFFFFFFFFFFFFFull;      // four -1 entries per lane
     uint32_t w = lane < 50 ? idmask[lane] : 0u;
     const unsigned c = (unsigned)__popc(w);                     // <= 32: six bits
     int pos = 0;
@@ -435,6 +448,8 @@ __device__ __forceinline__ void build_id_list(const uint32_t *dest, uint32_t *id
         const unsigned long long bal = __ballot((c >> k) & 1u);
         pos += (int)(__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)) << k);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (the -1 fill precedes the ids in program order)
+    __builtin_amdgcn_wave_barrier();
     while (w) {                                                 // this word's ids in ascending order
         const unsigned bidx = (unsigned)__builtin_ctz(w);
         w &= w - 1u;
@@ -444,14 +459,13 @@ __device__ __forceinline__ void build_id_list(const uint32_t *dest, uint32_t *id
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     reinterpret_cast<unsigned long long *>(out)[lane] = reinterpret_cast<const unsigned long long *>(rowbuf)[lane];
-    __builtin_amdgcn_wave_barrier();                            // (the buffers may be reused by this wave)
+    __builtin_amdgcn_wave_barrier();                            // (the row buffer may be reused by this wave)
 }
 
-// LDS of the fused list variant: the workgroup's destination boards and one list row per wave
+// LDS of the fused list variant: the id-ordered masks of the workgroup's 16 boards and one list row per wave
 template <bool LIST> struct ListMem { uint32_t pad; };
 template <> struct alignas(16) ListMem<true> {
-    uint32_t dest[16][HIVE_MASK_WORDS + 2];
-    uint32_t idmask[NW][52];
+    uint32_t idmask[16][52];
     alignas(8) int16_t rowbuf[NW][HIVE_LIST_CAP];
 };
 
@@ -514,6 +528,8 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         for (int i = tid; i < G * kCells; i += nthreads) (&sm.feat[0][0])[i] = 0ull;
     for (int i = tid; i < G * kCells / 4; i += nthreads)
         reinterpret_cast<uint4 *>(&sm.cellmask[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (LIST)
+        for (int i = tid; i < 16 * 52; i += nthreads) (&lm.idmask[0][0])[i] = 0u;
     if (tid == 0) { sm.done = 0; sm.pin_done = 0; sm.adj_done = 0; }
     if (tid < G) { sm.nlegal[tid] = 0; sm.pinmask[tid] = 0u; }
     if (tid < G * 4) reinterpret_cast<uint4 *>(sm.state[tid >> 2])[tid & 3] = rec_part;
@@ -576,10 +592,9 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         if (valid && mask != nullptr && (lane & 3) < 3)
             *reinterpret_cast<uint2 *>(mask + (gbase + bl) * HIVE_MASK_WORDS + wv * 6 + 2 * (lane & 3)) =
                 make_uint2(pc.D.lo, pc.D.hi);
-        if constexpr (LIST) {
-            if ((lane & 3) < 3)
-                *reinterpret_cast<uint2 *>(&lm.dest[bl][wv * 6 + 2 * (lane & 3)]) = make_uint2(pc.D.lo, pc.D.hi);
-        }
+        if constexpr (LIST)       // this quad's slot bits into its board's id-ordered mask (lane 3 of a quad holds zero)
+            scatter_slot_bits(lm.idmask[bl], (unsigned long long)pc.D.lo | ((unsigned long long)pc.D.hi << 32),
+                              4u * (unsigned)(lane & 3), (unsigned)wv);
         const int nd = __popc(pc.D.lo) + __popc(pc.D.hi);       // destination sets of different pieces are disjoint
         if (nd) atomicAdd(&sm.nlegal[bl], nd);
     }
@@ -638,7 +653,7 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         const int nbl = (int)((n - gbase) < G ? (n - gbase) : G);
         if (wave_id == 0 && count != nullptr && lane < nbl) count[gbase + lane] = sm.nlegal[lane];
         for (int b = wave_id; b < nbl; b += NW)
-            build_id_list(lm.dest[b], lm.idmask[wave_id], lm.rowbuf[wave_id], list + (gbase + b) * HIVE_LIST_CAP, lane);
+            emit_id_list(lm.idmask[b], lm.rowbuf[wave_id], list + (gbase + b) * HIVE_LIST_CAP, lane);
         return;
     }
     // ---------------- tail: the last wave to arrive writes the workgroup's results
@@ -671,7 +686,8 @@ hive_list_kernel(const uint32_t *__restrict__ mask, int n, int16_t *__restrict__
     const uint32_t *m = mask + b * HIVE_MASK_WORDS;
     dest[wv][lane] = m[lane];
     if (lane < HIVE_MASK_WORDS - 64) dest[wv][64 + lane] = m[64 + lane];
-    build_id_list(dest[wv], idmask[wv], rowbuf[wv], list + b * HIVE_LIST_CAP, lane);
+    transpose_dest_board(dest[wv], idmask[wv], lane);
+    emit_id_list(idmask[wv], rowbuf[wv], list + b * HIVE_LIST_CAP, lane);
 }
 
 // value encoders for the plane writer
