@@ -649,11 +649,14 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         // ---------------- fused encode_action: every wave stays, the 16 boards' lists are shared out between the 11 waves
         // (a raw barrier behind an LDS-only wait: __syncthreads() would also wait for the mask stores above to be
         // acknowledged by memory -- a microsecond or two nobody needs; only the LDS image must be complete)
+        HIVE_STAMP(5);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        HIVE_STAMP(6);
         const int nbl = (int)((n - gbase) < G ? (n - gbase) : G);
         if (wave_id == 0 && count != nullptr && lane < nbl) count[gbase + lane] = sm.nlegal[lane];
         for (int b = wave_id; b < nbl; b += NW)
             emit_id_list(lm.idmask[b], lm.rowbuf[wave_id], list + (gbase + b) * HIVE_LIST_CAP, lane);
+        HIVE_STAMP(7);
         return;
     }
     // ---------------- tail: the last wave to arrive writes the workgroup's results

@@ -38,3 +38,16 @@ print("            staged   piece work done   scattered   tail written (only the
 for w in range(11):
     print(f"  slot {w:2d}: " + "  ".join(f"{x:8.0f}" for x in s[w, :4]) + (f"   pin phase done {s[w, 4]:8.0f}" if s[w, 4] else ""))
 print(f"  mean workgroup end: {s[:, 3].sum():.0f} cycles")
+# the fused id-list variant (hive_piece_kernel<false, true>): arrival at the barrier, release, end of the wave
+lst = torch.empty((n, 256), dtype=torch.int16, device="cuda")
+for _ in range(20):
+    L.hive_movegen_launch(boards.data_ptr(), n, mask.data_ptr(), cnt.data_ptr(), lst.data_ptr(), None)
+torch.cuda.synchronize()
+s0 = stamps()
+for _ in range(10):
+    L.hive_movegen_launch(boards.data_ptr(), n, mask.data_ptr(), cnt.data_ptr(), lst.data_ptr(), None)
+torch.cuda.synchronize()
+s = (stamps() - s0) / 160.0
+print("fused id lists:  staged   piece work done   dest + scatter done   at barrier   released   wave end")
+for w in range(11):
+    print(f"  slot {w:2d}: " + "  ".join(f"{x:8.0f}" for x in (s[w, 0], s[w, 1], s[w, 2], s[w, 5], s[w, 6], s[w, 7])))
