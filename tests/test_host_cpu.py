@@ -345,7 +345,8 @@ def test_bench_gpus_flag_starts_the_ranks_itself(monkeypatch):
                         "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
     import torch
     if not torch.cuda.is_available():
-        assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+        # (the launcher tears the other rank down as soon as the first one exits: one or both messages appear)
+        assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") >= 1 and "torch.distributed" in r.stderr, r.stderr[-2000:]
     else:
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert r.returncode == 0 and line["n_gpus"] == 2
