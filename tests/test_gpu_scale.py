@@ -534,7 +534,7 @@ def test_finished_selfplay_games_replay_through_the_oracle(bf16_net):
     value and [game_len, counter] fields are consistent (woker/self_play.py:116-193)."""
     from oracle import oracle_py as O
     from hive_alphazero_amd import mcts, records
-    G, sims = 128, 8
+    G, sims = int(os.environ.get("HIVE_SOAK_GAMES", "128")), int(os.environ.get("HIVE_SOAK_SIMS", "8"))      # (soak runs: more of both)
     sp = mcts.SelfPlay(G, sims, bf16_net, seed=21, keep_records=True, game_ids=range(G), max_finished_kept=2 * G)
     games = []
     for _ in range(60):
@@ -561,7 +561,9 @@ def test_finished_selfplay_games_replay_through_the_oracle(bf16_net):
                 g.move(-1)
                 passes += 1
                 continue
-            assert abs(pol.sum() - 1.0) < 1e-4
+            # (when max W < 0 the policy is the masked prior renormalised the reference's way, p / (sum p + 1e-8),
+            # solo_play.py:304-313,372-373: with one legal move of prior 9e-5 that is 0.99989 -- seen in a 1024-game soak)
+            assert abs(pol.sum() - 1.0) < 2e-3, (gid, k, t, float(pol.sum()), len(legal), np.flatnonzero(pol).size)
             found = None
             if k + 1 < len(plies):
                 for a in legal:                    # (not only the policy's support: turns 1..6 resample with uniform noise)
