@@ -535,7 +535,8 @@ def test_finished_selfplay_games_replay_through_the_oracle(bf16_net):
     from oracle import oracle_py as O
     from hive_alphazero_amd import mcts, records
     G, sims = int(os.environ.get("HIVE_SOAK_GAMES", "128")), int(os.environ.get("HIVE_SOAK_SIMS", "8"))      # (soak runs: more of both)
-    sp = mcts.SelfPlay(G, sims, bf16_net, seed=21, keep_records=True, game_ids=range(G), max_finished_kept=2 * G)
+    slots = int(os.environ.get("HIVE_SOAK_SLOTS", "1"))             # leaves in flight per tree (virtual loss; BASELINE configs[4]: 4)
+    sp = mcts.SelfPlay(G, sims, bf16_net, seed=21, keep_records=True, game_ids=range(G), max_finished_kept=2 * G, slots=slots)
     games = []
     for _ in range(60):
         sp.play_ply()
