@@ -35,7 +35,7 @@ class TreeSearch:
 
     evaluator(planes[B,12,12,56]) -> (p fp32 [B,1584] softmax, v fp32 [B])."""
 
-    def __init__(self, games, sims, evaluator, device=None, slots=1, seed=0, plane_dtype=torch.bfloat16,
+    def __init__(self, games, sims, evaluator, device=None, slots=1, seed=0, plane_dtype=None,
                  c_puct=0.7, noise_eps=0.25, dirichlet_alpha=0.3, max_nodes=None, transpositions=True, mode=PUCT,
                  virtual_loss=None, max_game_length=None):
         """mode = PUCT: woker/solo_play.py::HivePlayer; mode = UCT: alpha_zero/MCTS_chess.py::UCT_search (plain tree, no
@@ -43,6 +43,10 @@ class TreeSearch:
         L = load()
         if L.hive_device_count() <= 0 or not torch.cuda.is_available():
             raise _lib.HiveError(-2, "no HIP device visible: hive_alphazero_amd has no CPU path")
+        if plane_dtype is None:      # the evaluator's own input type (the plane values 0 / 1 / turn are exact in all three)
+            plane_dtype = getattr(evaluator, "dtype", torch.bfloat16)
+            if plane_dtype not in _DT:
+                plane_dtype = torch.bfloat16
         self.L = L
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.games, self.sims, self.slots, self.evaluator = games, sims, slots, evaluator
@@ -174,7 +178,7 @@ class SelfPlay:
     `drain_finished()`; more than `max_finished_kept` undrained games are dropped and counted (`dropped_games`,
     one warning)."""
 
-    def __init__(self, games, sims, evaluator, device=None, slots=1, seed=0, plane_dtype=torch.bfloat16,
+    def __init__(self, games, sims, evaluator, device=None, slots=1, seed=0, plane_dtype=None,
                  keep_records=True, game_ids=None, max_finished_kept=1024, report_every=0, log=print):
         import itertools
         from .batch import BoardBatch

@@ -536,6 +536,10 @@ def test_finished_selfplay_games_replay_through_the_oracle(bf16_net):
     from hive_alphazero_amd import mcts, records
     G, sims = int(os.environ.get("HIVE_SOAK_GAMES", "128")), int(os.environ.get("HIVE_SOAK_SIMS", "8"))      # (soak runs: more of both)
     slots = int(os.environ.get("HIVE_SOAK_SLOTS", "1"))             # leaves in flight per tree (virtual loss; BASELINE configs[4]: 4)
+    if os.environ.get("HIVE_SOAK_DTYPE") == "fp16":                 # the fp16 leaf evaluator through the same chain
+        from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+        torch.manual_seed(0)
+        bf16_net = InferenceNet(ChessNet().cuda().eval(), dtype=torch.float16)
     sp = mcts.SelfPlay(G, sims, bf16_net, seed=21, keep_records=True, game_ids=range(G), max_finished_kept=2 * G, slots=slots)
     games = []
     for _ in range(60):
