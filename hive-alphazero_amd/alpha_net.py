@@ -412,6 +412,8 @@ class InferenceNet:
         # is captured (the default heuristic runs the 1024 x 18432 x 1584 policy FC at 178 us, the tuned pick at 92 us)
         self.tune_gemms = tune_gemms and dev.type == "cuda"
         self.fuse_blocks = True          # hive_nn_resblock: both convolutions of a residual block in one launch
+        self.split_streams = True        # leaf batches >= 512: two independent half-batch chains on two streams
+        self._side_stream = None
         if conv == "hip":
             from . import _lib
             self._L = _lib.load()
@@ -509,6 +511,32 @@ class InferenceNet:
                                         ctypes.c_void_p(tb.data_ptr()), ctypes.c_void_p(bufs[1].data_ptr()), B, 19, dt,
                                         self.tower, st))
             return bufs[1].permute(0, 3, 1, 2)
+        if self.fuse_blocks and self.split_streams and B >= 512 and B % 2 == 0:
+            # Boards are independent: only the 19 blocks of ONE board are ordered.  A single stream makes every block a
+            # chip-wide barrier (the launch boundary); two half-batch chains on two streams let one half's tail and ramp
+            # run under the other half's work: 246 instead of 260 us per block at 1024 boards, same bits
+            # (tools/two_stream_chain.py; four / eight chains are slower again: they de-phase the weight streams)
+            half = B // 2
+            main = torch.cuda.current_stream(self.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(self.device)
+            side = self._side_stream
+            side.wait_stream(main)
+            for lo, stream in ((0, main), (half, side)):
+                stp = ctypes.c_void_p(stream.cuda_stream)
+                cur = 0
+                for w1, b1, w2, b2 in self.h_blocks:
+                    nxt = (cur + 1) % 3
+                    check(self._L.hive_nn_resblock_dt(ctypes.c_void_p(bufs[cur][lo:].data_ptr()), ctypes.c_void_p(w1.data_ptr()),
+                                                      ctypes.c_void_p(b1.data_ptr()), ctypes.c_void_p(w2.data_ptr()),
+                                                      ctypes.c_void_p(b2.data_ptr()), ctypes.c_void_p(bufs[nxt][lo:].data_ptr()),
+                                                      half, dt, stp))
+                    cur = nxt
+            if not torch.cuda.is_current_stream_capturing():      # (a captured graph owns its memory pool)
+                for t in bufs:
+                    t.record_stream(side)
+            main.wait_stream(side)
+            return bufs[cur].permute(0, 3, 1, 2)
         for w1, b1, w2, b2 in self.h_blocks:
             if self.fuse_blocks:
                 s2 = bufs[(cur + 1) % 3]                                     # whole residual block in one launch

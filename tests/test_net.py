@@ -697,6 +697,16 @@ def test_inference_net_tower_forms_give_the_same_bits(dtype):
     x[..., 31] = 17.0
     ref = InferenceNet(net, dtype=dtype, tower=0)
     p0, v0 = ref(x)
+    # leaf batches >= 512 run as two half-batch chains on two streams: same bits as one chain, eagerly and replayed
+    xl = (torch.rand((640, 12, 12, 56), device="cuda") < 0.08).to(dtype)
+    one = InferenceNet(net, dtype=dtype, tune_gemms=False)
+    one.split_streams = False
+    two = InferenceNet(net, dtype=dtype, tune_gemms=False)
+    assert two.split_streams
+    pa, va = one(xl)
+    for _ in range(3):
+        pb, vb = two(xl)
+        assert torch.equal(pa, pb) and torch.equal(va, vb)
     engines = {t: InferenceNet(net, dtype=dtype, tower=t) for t in (1, 2, 3)}
     for t, inf in engines.items():
         p, v = inf(x)
