@@ -96,20 +96,23 @@ GFLOP_PER_LEAF = 6.560114816         # 3,280,057,408 MAC x 2 per board, SURVEY.m
 MFMA_PEAK_TFLOPS = 2500.0            # MI355X dense bf16/fp16 matrix peak, MI355X_MICROARCH.md
 
 
-def _leaf_accounting(hist, executed, el):
-    """MFMA roofline of a self-play window.  `executed` = boards the network evaluated (every simulation evaluates one
-    board per game slot, whatever the leaf turned out to be); `needed` = simulations whose leaf really was a position
-    to evaluate (root / new position), from the search's leaf histogram."""
+def _leaf_accounting(hist, launched, executed, el):
+    """MFMA roofline of a self-play window.  `launched` = rows of the leaf batches (every simulation hands the evaluator one
+    board per game slot, whatever the leaf turned out to be); `executed` = rows the tower really evaluated (the search flags
+    finished / capped / idle leaves and the kernels skip their boards: hive_search_leaf_need, mcts.TreeSearch.evals_run);
+    `needed` = simulations whose leaf was a position to evaluate (root / new position), from the search's leaf histogram."""
     needed = hist.get("root_evaluated", 0) + hist.get("expanded_evaluated", 0)
     tf = executed * GFLOP_PER_LEAF / el / 1e3
-    return {"leaf_kinds": hist, "leaf_evals_executed": executed, "leaf_evals_needed": needed,
+    return {"leaf_kinds": hist, "leaf_rows_launched": launched, "leaf_evals_executed": executed, "leaf_evals_needed": needed,
             "useful_leaf_fraction": round(needed / max(executed, 1), 4),
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / MFMA_PEAK_TFLOPS, 5), "traffic": None,
                          "achieved_needed_only": round(needed * GFLOP_PER_LEAF / el / 1e3, 2),
                          "frac_needed_only": round(needed * GFLOP_PER_LEAF / el / 1e3 / MFMA_PEAK_TFLOPS, 5),
-                         "note": "achieved counts the FLOPs executed (fixed batch of games x slots boards per simulation); "
-                                 "*_needed_only counts only leaves that had to be evaluated"}}
+                         "note": "achieved counts the FLOPs of the boards the tower evaluated (rows of finished / capped / idle "
+                                 "leaves are skipped by the kernels; the two head GEMMs, 2 % of a forward, still run on "
+                                 "every row and are counted for evaluated rows only); *_needed_only counts only leaves "
+                                 "the search's histogram books as evaluated"}}
 
 
 def selfplay_measure(args, rank, local_rank, world):
@@ -166,6 +169,7 @@ def selfplay_measure(args, rank, local_rank, world):
         sp = mcts.SelfPlay(args.games, args.sims, net, device=local_rank, slots=args.slots, seed=1234, keep_records=False,
                            game_ids=range(lo, lo + args.games))
         torch.cuda.synchronize()
+        ev0 = int(sp.search.evals_run.item())
         t0 = time.perf_counter()
         plies = 0
         while True:
@@ -175,13 +179,14 @@ def selfplay_measure(args, rank, local_rank, world):
                 break
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        executed = plies * args.games * args.sims           # every simulation evaluates one board per game slot
+        launched = plies * args.games * args.sims           # every simulation hands over one board per game slot
+        executed = int(sp.search.evals_run.item()) - ev0 if sp.search.skip_unread_rows else launched
         whole = {"games": sp.finished, "wall_s": round(el, 3), "plies_played": plies,
                  "games_per_min": round(sp.finished / el * 60.0, 2),
                  "mean_plies_per_game": round(sp.mean_game_length(), 2), "ms_per_ply": round(el / plies * 1e3, 2),
                  "illegal_moves": sp.env.illegal_count(),
                  "results": {"white": sp.white_wins, "black": sp.black_wins, "draw_or_cap": sp.draws}}
-        whole.update(_leaf_accounting(sp.leaf_histogram(), executed, el))
+        whole.update(_leaf_accounting(sp.leaf_histogram(), launched, executed, el))
         sp.close()
         out["whole_games"] = whole
         out["games_per_min"] = whole["games_per_min"]
@@ -224,7 +229,7 @@ def selfplay_measure(args, rank, local_rank, world):
         for _ in range(args.selfplay_warmup):
             sp.play_ply()
         torch.cuda.synchronize()
-        f0, h0 = sp.finished, sp.leaf_histogram()
+        f0, h0, ev0 = sp.finished, sp.leaf_histogram(), int(sp.search.evals_run.item())
         t0 = time.perf_counter()
         for _ in range(args.selfplay_plies):
             sp.play_ply()
@@ -234,7 +239,8 @@ def selfplay_measure(args, rank, local_rank, world):
         finished = sp.finished - f0
         h1 = sp.leaf_histogram()
         hist = {k: h1[k] - h0[k] for k in h1}
-        executed = args.selfplay_plies * args.games * args.sims
+        launched = args.selfplay_plies * args.games * args.sims
+        executed = int(sp.search.evals_run.item()) - ev0 if sp.search.skip_unread_rows else launched
         mean_len = (sum(sp.finished_lengths) / len(sp.finished_lengths) - 1.0) if sp.finished_lengths else 54.0
         steady = {"window_plies": args.selfplay_plies, "window_s": round(el, 3), "finished_games_in_window": finished,
                   "games_per_min_counted": round(finished / el * 60.0, 2),
@@ -242,7 +248,7 @@ def selfplay_measure(args, rank, local_rank, world):
                   "mean_plies_per_finished_game": round(mean_len, 2), "ms_per_ply": round(el / args.selfplay_plies * 1e3, 2),
                   "illegal_moves": sp.env.illegal_count(),
                   "results": {"white": sp.white_wins, "black": sp.black_wins, "draw_or_cap": sp.draws}}
-        steady.update(_leaf_accounting(hist, executed, el))
+        steady.update(_leaf_accounting(hist, launched, executed, el))
         sp.close()
         out["steady_state"] = steady
         out.setdefault("games_per_min", steady["games_per_min_counted"])

@@ -37,8 +37,10 @@ ABI_SYMBOLS = [
     "hive_search_set_roots", "hive_search_select", "hive_search_backup", "hive_search_policy",
     "hive_search_node_counts", "hive_search_set_transpositions", "hive_search_transposition_hits",
     "hive_search_set_game_ids", "hive_search_root_stats", "hive_search_leaf_histogram", "hive_search_sample_noise",
+    "hive_search_leaf_need",
     # include/hive_nn.h
     "hive_nn_conv3x3", "hive_nn_resblock", "hive_nn_conv3x3_dt", "hive_nn_resblock_dt", "hive_nn_tower",
+    "hive_nn_conv3x3_sel", "hive_nn_resblock_sel",
     "hive_nn_bn_workspace_floats", "hive_nn_bn_act_fwd", "hive_nn_bn_act_bwd",
     "hive_nn_pack_conv3x3_weights", "hive_nn_conv3x3_wgrad", "hive_nn_wgrad_workspace_floats",
 ]
@@ -121,6 +123,9 @@ def load():
     L.hive_nn_conv3x3_dt.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]
     L.hive_nn_resblock_dt.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
     L.hive_nn_tower.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.hive_nn_conv3x3_sel.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    L.hive_nn_resblock_sel.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
+    L.hive_search_leaf_need.argtypes = [vp, i32, vp, vp, vp, vp]
     f32, i64 = ctypes.c_float, ctypes.c_longlong
     L.hive_nn_bn_workspace_floats.restype = i32
     L.hive_nn_bn_act_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i64, i32, i32, vp]

@@ -484,27 +484,39 @@ class InferenceNet:
                 copy_into(getattr(self, name), value)
             torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
 
-    def _conv_hip(self, x, cin, w, b, res, out):
+    def _conv_hip(self, x, cin, w, b, res, out, need=None):
         import ctypes
         from ._lib import BF16, F16, check
         st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        check(self._L.hive_nn_conv3x3_dt(ctypes.c_void_p(x.data_ptr()), cin, ctypes.c_void_p(w.data_ptr()),
-                                         ctypes.c_void_p(b.data_ptr()),
-                                         ctypes.c_void_p(res.data_ptr()) if res is not None else None,
-                                         ctypes.c_void_p(out.data_ptr()), x.shape[0], 1,
-                                         BF16 if self.dtype == torch.bfloat16 else F16, st))
+        check(self._L.hive_nn_conv3x3_sel(ctypes.c_void_p(x.data_ptr()), cin, ctypes.c_void_p(w.data_ptr()),
+                                          ctypes.c_void_p(b.data_ptr()),
+                                          ctypes.c_void_p(res.data_ptr()) if res is not None else None,
+                                          ctypes.c_void_p(out.data_ptr()), x.shape[0], 1,
+                                          BF16 if self.dtype == torch.bfloat16 else F16,
+                                          ctypes.c_void_p(need.data_ptr()) if need is not None else None, st))
         return out
 
-    def _tower_hip(self, x_hwc):
+    def _tower_hip(self, x_hwc, need=None):
+        """need: int8[B] on the device or None -- boards flagged 0 are skipped by every kernel of the tower (their rows of
+        the activation buffers keep stale, finite values; the heads compute on them and nobody reads the result)."""
         B = x_hwc.shape[0]
         x_hwc = x_hwc.contiguous()
-        bufs = [torch.empty((B, 12, 12, 256), dtype=self.dtype, device=self.device) for _ in range(3)]
-        s = self._conv_hip(x_hwc, 56, self.h_stem[0], self.h_stem[1], None, bufs[0])
+        if need is not None and (self.tower or not self.fuse_blocks):
+            need = None                      # only the shipped launch-per-block form takes the selection
+        # a skipped board's rows must hold finite numbers: eager calls start from zeros; a captured graph owns its buffers
+        # for good and _call_locked replays it once with every board selected before the first real call
+        alloc = torch.zeros if need is not None and not torch.cuda.is_current_stream_capturing() else torch.empty
+        bufs = [alloc((B, 12, 12, 256), dtype=self.dtype, device=self.device) for _ in range(3)]
+        s = self._conv_hip(x_hwc, 56, self.h_stem[0], self.h_stem[1], None, bufs[0], need)
         cur = 0
         import ctypes
         from ._lib import BF16, F16, check
         dt = BF16 if self.dtype == torch.bfloat16 else F16
         st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+        def needp(lo):
+            return ctypes.c_void_p(need.data_ptr() + lo) if need is not None else None
+
         if self.tower:
             tw, tb = self.h_tower
             check(self._L.hive_nn_tower(ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(tw.data_ptr()),
@@ -527,10 +539,10 @@ class InferenceNet:
                 cur = 0
                 for w1, b1, w2, b2 in self.h_blocks:
                     nxt = (cur + 1) % 3
-                    check(self._L.hive_nn_resblock_dt(ctypes.c_void_p(bufs[cur][lo:].data_ptr()), ctypes.c_void_p(w1.data_ptr()),
-                                                      ctypes.c_void_p(b1.data_ptr()), ctypes.c_void_p(w2.data_ptr()),
-                                                      ctypes.c_void_p(b2.data_ptr()), ctypes.c_void_p(bufs[nxt][lo:].data_ptr()),
-                                                      half, dt, stp))
+                    check(self._L.hive_nn_resblock_sel(ctypes.c_void_p(bufs[cur][lo:].data_ptr()), ctypes.c_void_p(w1.data_ptr()),
+                                                       ctypes.c_void_p(b1.data_ptr()), ctypes.c_void_p(w2.data_ptr()),
+                                                       ctypes.c_void_p(b2.data_ptr()), ctypes.c_void_p(bufs[nxt][lo:].data_ptr()),
+                                                       half, dt, needp(lo), stp))
                     cur = nxt
             if not torch.cuda.is_current_stream_capturing():      # (a captured graph owns its memory pool)
                 for t in bufs:
@@ -540,9 +552,10 @@ class InferenceNet:
         for w1, b1, w2, b2 in self.h_blocks:
             if self.fuse_blocks:
                 s2 = bufs[(cur + 1) % 3]                                     # whole residual block in one launch
-                check(self._L.hive_nn_resblock_dt(ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(w1.data_ptr()),
-                                                  ctypes.c_void_p(b1.data_ptr()), ctypes.c_void_p(w2.data_ptr()),
-                                                  ctypes.c_void_p(b2.data_ptr()), ctypes.c_void_p(s2.data_ptr()), B, dt, st))
+                check(self._L.hive_nn_resblock_sel(ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(w1.data_ptr()),
+                                                   ctypes.c_void_p(b1.data_ptr()), ctypes.c_void_p(w2.data_ptr()),
+                                                   ctypes.c_void_p(b2.data_ptr()), ctypes.c_void_p(s2.data_ptr()), B, dt,
+                                                   needp(0), st))
                 s, cur = s2, (cur + 1) % 3
             else:
                 o = self._conv_hip(s, 256, w1, b1, None, bufs[(cur + 1) % 3])
@@ -550,10 +563,10 @@ class InferenceNet:
                 s, cur = s2, (cur + 2) % 3
         return s.permute(0, 3, 1, 2)             # NCHW view with channels-last strides
 
-    def _forward(self, x_hwc):
+    def _forward(self, x_hwc, need=None):
         # x_hwc: [B,12,12,56] in self.dtype; viewed as NCHW with channels-last strides (zero copy)
         if self.conv == "hip":
-            s = self._tower_hip(x_hwc)
+            s = self._tower_hip(x_hwc, need)
         else:
             x = x_hwc.permute(0, 3, 1, 2)
             s = F.relu(F.conv2d(x, self.stem[0], self.stem[1], padding=1))
@@ -592,21 +605,27 @@ class InferenceNet:
         finally:
             tn.tuning_enable(False)
 
-    def __call__(self, planes_hwc):
+    accepts_need = True          # __call__ takes the row selection of hive_search_leaf_need (mcts.TreeSearch asks for this)
+
+    def __call__(self, planes_hwc, need=None):
+        """need: int8[B] on the device (1 = this row's p / v will be read) or None = every row.  Rows flagged 0 come back
+        with unspecified (finite) numbers; the tower's kernels skip their boards (hive_nn_resblock_sel)."""
         with self._lock:
-            p, v = self._call_locked(planes_hwc)
+            p, v = self._call_locked(planes_hwc, need if self.conv == "hip" else None)
             return (p.clone(), v.clone()) if self.use_graph else (p, v)
 
-    def _call_locked(self, planes_hwc):
+    def _call_locked(self, planes_hwc, need=None):
         B = planes_hwc.shape[0]
         if planes_hwc.dtype != self.dtype:
             planes_hwc = planes_hwc.to(self.dtype)
         if not self.use_graph:
-            return self._forward(planes_hwc)
+            return self._forward(planes_hwc, need)
+        hip = self.conv == "hip"
         g = self._graphs.get(B)
         if g is None:
             static_in = torch.zeros_like(planes_hwc)
             static_in.copy_(planes_hwc)
+            static_need = torch.ones((B,), dtype=torch.int8, device=self.device) if hip else None
             try:
                 s = torch.cuda.Stream(self.device)
                 s.wait_stream(torch.cuda.current_stream(self.device))
@@ -614,12 +633,14 @@ class InferenceNet:
                     if self.tune_gemms and B >= 256:
                         self._tune(static_in)
                     for _ in range(2):
-                        self._forward(static_in)
+                        self._forward(static_in, static_need)
                 torch.cuda.current_stream(self.device).wait_stream(s)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    out = self._forward(static_in)
-                g = (graph, static_in, out)
+                    out = self._forward(static_in, static_need)
+                if hip:
+                    graph.replay()             # every board selected: the graph's activation buffers now hold finite rows
+                g = [graph, static_in, out, static_need, True]
                 self._graphs[B] = g
             finally:
                 if self._tunable_before is not None:
@@ -629,7 +650,13 @@ class InferenceNet:
                     import torch.cuda.tunable as tn
                     tn.enable(self._tunable_before)
                     self._tunable_before = None
-        graph, static_in, out = g
+        graph, static_in, out, static_need, all_rows = g
         static_in.copy_(planes_hwc)
+        if need is not None:
+            static_need.copy_(need)
+            g[4] = False
+        elif not all_rows:
+            static_need.fill_(1)
+            g[4] = True
         graph.replay()
         return out

@@ -166,8 +166,9 @@ __device__ __forceinline__ void conv_taps(const unsigned char *lds, unsigned zof
 template <typename E, int CINP, bool RES, int NWAVE>
 __global__ void __launch_bounds__(NWAVE * 64, NWAVE / 2)
 conv3x3_kernel(const typename E::T *__restrict__ X, int cin, const typename E::T *__restrict__ W, const float *__restrict__ bias,
-               const typename E::T *__restrict__ R, typename E::T *__restrict__ Y, int relu)
+               const typename E::T *__restrict__ R, typename E::T *__restrict__ Y, int relu, const int8_t *__restrict__ need)
 {
+    if (need && !need[blockIdx.x]) return;      // a row nobody will read (hive_search_leaf_need): its output keeps what it held
     typedef typename E::T T;
     typedef typename E::v8 v8;
     typedef typename E::v4 v4;
@@ -313,8 +314,10 @@ conv3x3_kernel(const typename E::T *__restrict__ X, int cin, const typename E::T
 template <typename E>
 __global__ void __launch_bounds__(256, 2)
 resblock_kernel(const typename E::T *__restrict__ X, const typename E::T *__restrict__ W1, const float *__restrict__ b1,
-                const typename E::T *__restrict__ W2, const float *__restrict__ b2, typename E::T *__restrict__ Y)
+                const typename E::T *__restrict__ W2, const float *__restrict__ b2, typename E::T *__restrict__ Y,
+                const int8_t *__restrict__ need)
 {
+    if (need && !need[blockIdx.x]) return;      // workgroup-uniform, before any barrier
     typedef typename E::T T;
     typedef typename E::v8 v8;
     typedef typename E::v4 v4;
@@ -482,7 +485,7 @@ tower_kernel(const typename E::T *__restrict__ X, const typename E::T *__restric
 
 template <typename E>
 static int launch_conv(const void *x, int cin, const void *w, const float *bias, const void *residual, void *y, int batch,
-                       int relu, hipStream_t s)
+                       int relu, const int8_t *need, hipStream_t s)
 {
     typedef typename E::T T;
     const T *X = (const T *)x, *Wt = (const T *)w, *R = (const T *)residual;
@@ -490,11 +493,11 @@ static int launch_conv(const void *x, int cin, const void *w, const float *bias,
     constexpr int NWV = HIVE_CONV_WAVES;
     dim3 grid((unsigned)batch), block(NWV * 64);
     if (cin == 256) {
-        if (R) hipLaunchKernelGGL((conv3x3_kernel<E, 256, true, NWV>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
-        else hipLaunchKernelGGL((conv3x3_kernel<E, 256, false, NWV>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
+        if (R) hipLaunchKernelGGL((conv3x3_kernel<E, 256, true, NWV>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu, need);
+        else hipLaunchKernelGGL((conv3x3_kernel<E, 256, false, NWV>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu, need);
     } else {
-        if (R) hipLaunchKernelGGL((conv3x3_kernel<E, 64, true, NWV>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
-        else hipLaunchKernelGGL((conv3x3_kernel<E, 64, false, NWV>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu);
+        if (R) hipLaunchKernelGGL((conv3x3_kernel<E, 64, true, NWV>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu, need);
+        else hipLaunchKernelGGL((conv3x3_kernel<E, 64, false, NWV>), grid, block, 0, s, X, cin, Wt, bias, R, Y, relu, need);
     }
     return 0;
 }
@@ -505,17 +508,23 @@ using namespace hive;
 
 static bool dtype_ok(int dtype) { return dtype == HIVE_BF16 || dtype == HIVE_F16; }
 
-extern "C" int hive_nn_conv3x3_dt(const void *x, int cin, const void *w, const float *bias, const void *residual, void *y,
-                                  int batch, int relu, int dtype, void *stream)
+extern "C" int hive_nn_conv3x3_sel(const void *x, int cin, const void *w, const float *bias, const void *residual, void *y,
+                                   int batch, int relu, int dtype, const int8_t *need, void *stream)
 {
     if (!x || !w || !bias || !y || batch <= 0) return set_error(HIVE_E_ARG, "hive_nn_conv3x3: bad argument");
     if (cin != 256 && cin != 56) return set_error(HIVE_E_ARG, "hive_nn_conv3x3: cin must be 56 or 256");
     if (!dtype_ok(dtype)) return set_error(HIVE_E_ARG, "hive_nn_conv3x3: dtype must be HIVE_BF16 or HIVE_F16");
-    if (dtype == HIVE_BF16) launch_conv<Bf16>(x, cin, w, bias, residual, y, batch, relu, (hipStream_t)stream);
-    else launch_conv<F16>(x, cin, w, bias, residual, y, batch, relu, (hipStream_t)stream);
+    if (dtype == HIVE_BF16) launch_conv<Bf16>(x, cin, w, bias, residual, y, batch, relu, need, (hipStream_t)stream);
+    else launch_conv<F16>(x, cin, w, bias, residual, y, batch, relu, need, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(HIVE_E_DEVICE, std::string("hive_nn_conv3x3: ") + hipGetErrorString(e));
     return HIVE_OK;
+}
+
+extern "C" int hive_nn_conv3x3_dt(const void *x, int cin, const void *w, const float *bias, const void *residual, void *y,
+                                  int batch, int relu, int dtype, void *stream)
+{
+    return hive_nn_conv3x3_sel(x, cin, w, bias, residual, y, batch, relu, dtype, nullptr, stream);
 }
 
 extern "C" int hive_nn_conv3x3(const void *x, int cin, const void *w, const float *bias, const void *residual, void *y,
@@ -524,21 +533,27 @@ extern "C" int hive_nn_conv3x3(const void *x, int cin, const void *w, const floa
     return hive_nn_conv3x3_dt(x, cin, w, bias, residual, y, batch, relu, HIVE_BF16, stream);
 }
 
-extern "C" int hive_nn_resblock_dt(const void *x, const void *w1, const float *b1, const void *w2, const float *b2, void *y,
-                                   int batch, int dtype, void *stream)
+extern "C" int hive_nn_resblock_sel(const void *x, const void *w1, const float *b1, const void *w2, const float *b2, void *y,
+                                    int batch, int dtype, const int8_t *need, void *stream)
 {
     if (!x || !w1 || !b1 || !w2 || !b2 || !y || batch <= 0 || x == y)
         return set_error(HIVE_E_ARG, "hive_nn_resblock: bad argument (y must not alias x)");
     if (!dtype_ok(dtype)) return set_error(HIVE_E_ARG, "hive_nn_resblock: dtype must be HIVE_BF16 or HIVE_F16");
     if (dtype == HIVE_BF16)
         hipLaunchKernelGGL(resblock_kernel<Bf16>, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)x,
-                           (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (__bf16 *)y);
+                           (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (__bf16 *)y, need);
     else
         hipLaunchKernelGGL(resblock_kernel<F16>, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)x,
-                           (const _Float16 *)w1, b1, (const _Float16 *)w2, b2, (_Float16 *)y);
+                           (const _Float16 *)w1, b1, (const _Float16 *)w2, b2, (_Float16 *)y, need);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(HIVE_E_DEVICE, std::string("hive_nn_resblock: ") + hipGetErrorString(e));
     return HIVE_OK;
+}
+
+extern "C" int hive_nn_resblock_dt(const void *x, const void *w1, const float *b1, const void *w2, const float *b2, void *y,
+                                   int batch, int dtype, void *stream)
+{
+    return hive_nn_resblock_sel(x, w1, b1, w2, b2, y, batch, dtype, nullptr, stream);
 }
 
 extern "C" int hive_nn_resblock(const void *x, const void *w1, const float *b1, const void *w2, const float *b2, void *y,

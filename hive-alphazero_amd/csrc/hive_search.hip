@@ -568,6 +568,29 @@ search_policy_kernel(SearchDev S, float *__restrict__ policy, int32_t *__restric
     }
 }
 
+// hive_search_leaf_need: which of the selected leaves will search_backup_kernel ask the network about?  Exactly the
+// conditions of that kernel: a finished game (PUCT), a leaf at the length cap, a revisited terminal node, a collision and an
+// idle tree take their value from elsewhere -- the evaluator may skip their rows.
+__global__ void __launch_bounds__(256)
+search_need_kernel(SearchDev S, int slots, const HiveBoard *__restrict__ leaf_boards, const int8_t *__restrict__ over,
+                   int8_t *__restrict__ need, unsigned long long *__restrict__ total)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)slots * S.G;
+    bool want = false;
+    if (i < n) {
+        const int kind = S.leaf_kind[i];
+        want = kind == LEAF_ROOT || kind == LEAF_EXPAND;
+        if (want && S.prm.mode != HIVE_SEARCH_UCT)
+            want = !over[i] && (int)leaf_boards[i].turn < S.prm.max_game_length;
+        need[i] = want ? 1 : 0;
+    }
+    if (total) {
+        const unsigned long long w = __ballot(want);
+        if ((threadIdx.x & 63) == 0 && w) atomicAdd(total, (unsigned long long)__popcll(w));
+    }
+}
+
 // UCTNode.child_number_visits / child_total_value / child_priors of the root (MCTS_chess.py:33-35) as dense action-indexed rows
 __global__ void __launch_bounds__(256)
 search_root_stats_kernel(SearchDev S, float *__restrict__ visits, float *__restrict__ total_value, float *__restrict__ priors)
@@ -779,6 +802,18 @@ int hive_search_backup(HiveSearch *s, int slot, const HiveBoard *leaf_boards, co
     S_TRY(hipSetDevice(s->device));
     hipLaunchKernelGGL(search_backup_kernel, wave_grid(s->d.G), dim3(256), 0, s->stream, s->d, slot, leaf_boards, leaf_hist,
                        leaf_mask, over, winner, p, v);
+    S_TRY(hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_search_leaf_need(HiveSearch *s, int slots, const HiveBoard *leaf_boards, const int8_t *over, int8_t *need,
+                          uint64_t *total)
+{
+    if (!s || !leaf_boards || !over || !need || slots < 1 || slots > s->d.L) return hive::set_error(HIVE_E_ARG, "bad argument");
+    S_TRY(hipSetDevice(s->device));
+    const long long n = (long long)slots * s->d.G;
+    hipLaunchKernelGGL(search_need_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->d, slots, leaf_boards,
+                       over, need, reinterpret_cast<unsigned long long *>(total));
     S_TRY(hipGetLastError());
     return HIVE_OK;
 }

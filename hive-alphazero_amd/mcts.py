@@ -37,7 +37,7 @@ class TreeSearch:
 
     def __init__(self, games, sims, evaluator, device=None, slots=1, seed=0, plane_dtype=None,
                  c_puct=0.7, noise_eps=0.25, dirichlet_alpha=0.3, max_nodes=None, transpositions=True, mode=PUCT,
-                 virtual_loss=None, max_game_length=None):
+                 virtual_loss=None, max_game_length=None, skip_unread_rows=True):
         """mode = PUCT: woker/solo_play.py::HivePlayer; mode = UCT: alpha_zero/MCTS_chess.py::UCT_search (plain tree, no
         noise, no length cap; with one slot the virtual loss is 0 so that W sums exactly like the sequential reference)."""
         L = load()
@@ -80,6 +80,13 @@ class TreeSearch:
         self.action = torch.zeros((games,), dtype=torch.int32, device=dev)
         self.sum_n = torch.zeros((games,), dtype=torch.int32, device=dev)
         self.root_planes = None
+        # rows of the leaf batch whose prediction the backup never reads (finished games, length cap, collisions, idle
+        # trees: the reference does not call its model for them either, solo_play.py:169-197) are skipped by an evaluator
+        # that can (InferenceNet: its tower kernels take the flags); evals_run counts the rows that were evaluated
+        self.skip_unread_rows = bool(skip_unread_rows) and bool(getattr(evaluator, "accepts_need", False))
+        self.leaf_need = torch.ones((n,), dtype=torch.int8, device=dev)
+        self.evals_run = torch.zeros((1,), dtype=torch.int64, device=dev)
+        self.evals_launched = 0
 
     def close(self):
         if getattr(self, "_h", None):
@@ -114,7 +121,13 @@ class TreeSearch:
                                      _p(self.leaf_over), _p(self.leaf_winner), s))
             if first and keep_root_planes:
                 self.root_planes = self.workspace[:G * 144].clone()
-            p, v = self.evaluator(self.planes[:n])
+            if self.skip_unread_rows:
+                check(L.hive_search_leaf_need(self._h, k, _p(self.leaf_boards), _p(self.leaf_over), _p(self.leaf_need),
+                                              _p(self.evals_run)))
+                p, v = self.evaluator(self.planes[:n], need=self.leaf_need[:n])
+            else:
+                p, v = self.evaluator(self.planes[:n])
+            self.evals_launched += n
             p = p.float().contiguous()
             v = v.float().contiguous().view(-1)
             for sl in range(k):

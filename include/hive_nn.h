@@ -42,6 +42,15 @@ int hive_nn_conv3x3_dt(const void *x, int cin, const void *w, const float *bias,
 int hive_nn_resblock_dt(const void *x, const void *w1, const float *b1, const void *w2, const float *b2, void *y,
                         int batch, int dtype, void *stream);
 
+/* The same with a row selection: need = int8[batch] on the device (hive_search_leaf_need) or NULL; the workgroup of a
+ * board with need[b] == 0 returns at once and that board's rows of y keep whatever they held.  What the reference does by
+ * never calling its model for a finished or capped leaf (solo_play.py:169-197): the leaf batch keeps its shape, the
+ * skipped boards cost a workgroup launch instead of 2 x 170 MFLOP x blocks. */
+int hive_nn_conv3x3_sel(const void *x, int cin, const void *w, const float *bias, const void *residual, void *y,
+                        int batch, int relu, int dtype, const int8_t *need, void *stream);
+int hive_nn_resblock_sel(const void *x, const void *w1, const float *b1, const void *w2, const float *b2, void *y,
+                         int batch, int dtype, const int8_t *need, void *stream);
+
 /* The whole residual tower (alpha_net.py:87-99, the loop over res_0 .. res_{nblocks-1}) in ONE launch:
  *   x, y   [batch][144][256] channels-last (dtype as above); y must not alias x
  *   w      [2 * nblocks][9][8][16][64][8]: the fragment-major weights of conv1, conv2 of block 0, conv1 of block 1, ...

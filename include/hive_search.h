@@ -79,6 +79,15 @@ int hive_search_backup(HiveSearch *s, int slot, const HiveBoard *leaf_boards, co
                        const uint32_t *leaf_mask, const int8_t *over, const int8_t *winner, const float *p,
                        const float *v);
 
+/* Which leaves of the last hive_search_select calls (slots 0 .. slots-1, after hive_leaf_launch filled `over`) will
+ * hive_search_backup ask the evaluator about?  need = int8[slots * games] (1 = the network's p / v of that row are read;
+ * 0 = finished game, length cap, revisited terminal node, collision or idle tree: solo_play.py:169-183 take those values
+ * without a prediction, and the reference never calls its model for them -- api_hive.py:62-69 is reached only from
+ * solo_play.py:188-197).  leaf_boards / over are the full [slots * games] arrays.  total (may be NULL): uint64 device
+ * counter, the number of rows flagged 1 is ADDED to it.  Feed `need` to hive_nn_conv3x3_sel / hive_nn_resblock_sel. */
+int hive_search_leaf_need(HiveSearch *s, int slots, const HiveBoard *leaf_boards, const int8_t *over, int8_t *need,
+                          uint64_t *total);
+
 /* HivePlayer.calc_policy + apply_temperature (solo_play.py:337-374) at the roots:
  * policy = float[games][1584] visit distribution (may be NULL), action = int32[games] (argmax, -1 = pass),
  * sum_n = int32[games] (may be NULL).  selfplay != 0 adds self_play.py:139-157: for turn <= 6 the

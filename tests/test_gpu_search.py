@@ -427,3 +427,43 @@ def test_selfplay_rows_equal_reference_written_rows():
         assert value == row["v"] and lens == row["lens"]
         assert abs(sum(policy) - 1.0) < 1e-4
     sp.close()
+
+
+@pytest.mark.gpu
+def test_skipping_unread_leaf_rows_does_not_change_the_search():
+    """TreeSearch(skip_unread_rows=True) (default with InferenceNet): hive_search_leaf_need flags the leaves whose
+    prediction hive_search_backup never reads (finished games, length cap, collisions, idle trees) and the evaluator's
+    kernels skip those boards.  Same trees, same noise, late-game positions (many finished leaves), one and four leaves
+    in flight: actions, visit policies and visit totals must be IDENTICAL to the search that evaluates every row, and the
+    rows-evaluated counter must sit between the histogram's "expanded and evaluated" and its "network may have been asked" kinds."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd import batch, mcts, playout
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    torch.manual_seed(0)
+    net = ChessNet().cuda().eval()
+    inf = InferenceNet(net, dtype=torch.bfloat16, tune_gemms=False)
+    G, sims = 192, 40
+    boards = playout.random_positions(G, seed=23)
+    B = batch.BoardBatch(G)
+    B.import_state(boards)
+    rb, rh = B.export_state()
+    active = torch.ones((G,), dtype=torch.int8, device="cuda")
+    active[::7] = 0                                              # idle trees
+    for slots in (1, 4):
+        out = {}
+        for skip in (False, True):
+            ts = mcts.TreeSearch(G, sims, inf, slots=slots, seed=9, skip_unread_rows=skip)
+            assert ts.skip_unread_rows == skip
+            action, policy, sum_n = ts.search(rb, rh, active=active, selfplay=True)
+            hist = ts.leaf_histogram().sum(0).cpu().numpy()
+            out[skip] = (action.clone(), policy.clone(), sum_n.clone(), hist, int(ts.evals_run.item()), ts.evals_launched)
+            ts.close()
+        a0, p0, n0, h0, _, launched0 = out[False]
+        a1, p1, n1, h1, run1, launched1 = out[True]
+        assert torch.equal(a0, a1) and torch.equal(p0, p1) and torch.equal(n0, n1), slots
+        assert (h0 == h1).all() and launched0 == launched1
+        # root (also a root AT the length cap), expanded + evaluated, created meanwhile by another slot (also a finished one)
+        asked = int(h1[1] + h1[2] + h1[7])
+        print(f"slots {slots}: {launched1} rows launched, {run1} evaluated, histogram says {asked} were read; kinds {h1.tolist()}")
+        assert int(h1[2]) <= run1 <= asked and run1 < launched1
+    B.close()

@@ -722,3 +722,48 @@ def test_inference_net_tower_forms_give_the_same_bits(dtype):
         inf.refresh(net2)
         p, v = inf(x)
         assert torch.equal(p, p1) and torch.equal(v, v1), t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_inference_net_row_selection_keeps_the_selected_rows_bit_identical(dtype):
+    """InferenceNet(planes, need=flags): the tower's kernels skip the boards flagged 0 (hive_nn_conv3x3_sel /
+    hive_nn_resblock_sel; what the reference does by never calling its model for a finished or capped leaf,
+    solo_play.py:169-197).  The rows flagged 1 must carry exactly the bits of the unselected forward -- eagerly, through
+    the captured graph, on the two-stream form (>= 512 rows) and when the selection changes between replays -- and the
+    skipped rows must stay finite."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    torch.manual_seed(3)
+    net = ChessNet().cuda().eval()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for B in (37, 640):
+        x = (torch.rand((B, 12, 12, 56), device="cuda", generator=gen) < 0.08).to(dtype)
+        full = InferenceNet(net, dtype=dtype, tune_gemms=False)
+        p0, v0 = full(x)
+        for use_graph in (False, True):
+            inf = InferenceNet(net, dtype=dtype, tune_gemms=False, use_graph=use_graph)
+            for frac in (0.9, 0.5, 1.0, 0.0, 0.97):
+                need = (torch.rand((B,), device="cuda", generator=gen) < frac).to(torch.int8)
+                p, v = inf(x, need=need)
+                sel = need.bool()
+                assert torch.equal(p[sel], p0[sel]) and torch.equal(v[sel], v0[sel]), (B, use_graph, frac)
+                assert torch.isfinite(p).all() and torch.isfinite(v).all()
+            p, v = inf(x)                                     # and back to every row
+            assert torch.equal(p, p0) and torch.equal(v, v0)
+    # the selection really skips work: all rows off must be much cheaper than all rows on
+    inf = InferenceNet(net, dtype=dtype, tune_gemms=False)
+    x = (torch.rand((1024, 12, 12, 56), device="cuda", generator=gen) < 0.08).to(dtype)
+    on, off = torch.ones(1024, dtype=torch.int8, device="cuda"), torch.zeros(1024, dtype=torch.int8, device="cuda")
+    def ms(need):
+        inf(x, need=need)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            inf(x, need=need)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 3
+    t_on, t_off = ms(on), ms(off)
+    print(f"1024-row forward: every row {t_on:.3f} ms, no row {t_off:.3f} ms")
+    assert t_off < 0.25 * t_on

@@ -33,14 +33,36 @@ def two(parts=2):
         s.wait_event(ev)
         chain(k * (B // parts), B // parts, s)
         e = torch.cuda.Event(); e.record(s); main.wait_event(e)
+def two_upto(count):
+    """what a compacted leaf batch would run: boards [0, 512) and [512, count) -- the second chain is shorter"""
+    ev = torch.cuda.Event(); ev.record(main)
+    for k, s in enumerate(pool[:2]):
+        lo = k * (B // 2)
+        n = min(B // 2, count - lo)
+        s.wait_event(ev)
+        if n > 0:
+            chain(lo, n, s)
+        e = torch.cuda.Event(); e.record(s); main.wait_event(e)
+def two_even(count):
+    """the same boards split evenly"""
+    ev = torch.cuda.Event(); ev.record(main)
+    h = (count + 1) // 2
+    for k, s in enumerate(pool[:2]):
+        s.wait_event(ev)
+        chain(k * h, min(h, count - k * h), s)
+        e = torch.cuda.Event(); e.record(s); main.wait_event(e)
 ref = None
 forms = (("one stream x 1024", one), ("two streams x 512", two), ("four streams x 256", lambda: two(4)), ("eight streams x 128", lambda: two(8)))
+if len(sys.argv) > 1 and sys.argv[1] == "counts":
+    forms = (("two streams x 512", two),) + tuple((f"512 + {c - 512}", (lambda c=c: two_upto(c))) for c in (992, 960, 928, 896, 768)) \
+        + tuple((f"2 x {c // 2}", (lambda c=c: two_even(c))) for c in (992, 960, 896, 768))
 times = {k: [] for k, _ in forms}
 for name, fn in forms:
     fn(); torch.cuda.synchronize()
     out = (y1 if NBLK % 2 else y2).clone()
     ref = out if ref is None else ref
-    print(name, "same bits as the single chain:", bool(torch.equal(out, ref)))
+    if "+" not in name and " x " in name and not name.startswith("2 x"):
+        print(name, "same bits as the single chain:", bool(torch.equal(out, ref)))
 for _ in range(8):
     for name, fn in forms:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
