@@ -194,19 +194,21 @@ def selfplay_measure(args, rank, local_rank, world):
     if args.whole_games and args.records:
         # the same whole games with the per-ply records ON (woker/self_play.py:159-160: a row per ply; :178-193 values at the
         # end): features + policy + mover copied to the host every ply, finished games cut out and handed over
-        # (drain_finished) -- what a producer does; the engine is otherwise identical (same seed, same game ids)
+        # (drain_finished_packed: the array batches SelfPlayWorker's children send and play_<ts>.npz holds) -- what a
+        # producer does; the engine is otherwise identical (same seed, same game ids)
         lo = rank * args.games
         sp = mcts.SelfPlay(args.games, args.sims, net, device=local_rank, slots=args.slots, seed=1234, keep_records=True,
-                           game_ids=range(lo, lo + args.games), max_finished_kept=2 * args.games)
+                           game_ids=range(lo, lo + args.games), max_finished_kept=2 * args.games, packed_records=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         plies, games_out, rows_out = 0, 0, 0
         while True:
             sp.play_ply()
             plies += 1
-            for entry in sp.drain_finished():
-                games_out += 1
-                rows_out += len(entry[1])
+            batch = sp.drain_finished_packed()
+            if batch is not None:
+                games_out += len(batch["game_val"])
+                rows_out += len(batch["meta"])
             if sp.running() == 0 or plies > 60:
                 break
         torch.cuda.synchronize()
@@ -281,7 +283,7 @@ def selfplay_worker_measure(args, local_rank):
         t1 = time.time()
         ready = w.ready_at.get(0, t0)
         files = [os.path.getsize(f) for f in w.files]
-        rows = sum(len(e[1]) for e in res.values())
+        rows = int(sum(w.game_lens))
         return {"games": len(res), "rows": rows, "files": len(files), "file_bytes": int(sum(files)),
                 "wall_s_total": round(t1 - t0, 3), "child_startup_s": round(ready - t0, 3),
                 "wall_s_playing": round(t1 - ready, 3),

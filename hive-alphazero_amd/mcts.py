@@ -189,10 +189,12 @@ class SelfPlay:
 
     Finished games pile up in `finished_games` as (value_white, plies, game_id) until the caller takes them with
     `drain_finished()`; more than `max_finished_kept` undrained games are dropped and counted (`dropped_games`,
-    one warning)."""
+    one warning).  packed_records=True collects them as packed batches instead (records.pack_games' arrays, built with
+    array operations straight from the per-ply host copies: no per-row Python objects, sparse policies) --
+    `drain_finished_packed()`; what SelfPlayWorker's children send to the parent."""
 
     def __init__(self, games, sims, evaluator, device=None, slots=1, seed=0, plane_dtype=None,
-                 keep_records=True, game_ids=None, max_finished_kept=1024, report_every=0, log=print):
+                 keep_records=True, game_ids=None, max_finished_kept=1024, report_every=0, log=print, packed_records=False):
         import itertools
         from .batch import BoardBatch
         self.games, self.sims = games, sims
@@ -216,6 +218,9 @@ class SelfPlay:
         self._start_ply = [0] * games   # ply counter at which the game in each slot started
         self._unlogged = [False] * games   # opening plies of this slot's game were played outside play_ply (stagger)
         self.finished_games = []
+        self.packed_records = bool(packed_records)
+        self.finished_packed = []    # packed batches of finished games (packed_records=True)
+        self._packed_waiting = 0
         self.max_finished_kept = max_finished_kept
         self.dropped_games = self.unrecorded_games = 0
         self.report_every, self._log_fn, self._reported = report_every, log, 0
@@ -298,28 +303,97 @@ class SelfPlay:
         """self_play.py:165-191: value_white = +1 / -1 / 0; a draw or the length cap scores -1 for both."""
         import warnings
         self._log_ready()
+        keep = []                        # (slot, first logged ply, value_white, game id)
         for s in slots:
             start, self._start_ply[s] = self._start_ply[s], self.plies
             unlogged, self._unlogged[s] = self._unlogged[s], False
             if unlogged:
                 self.unrecorded_games += 1
                 continue
-            if len(self.finished_games) >= self.max_finished_kept:
+            if len(self.finished_games) + self._packed_waiting + len(keep) >= self.max_finished_kept:
                 if self.dropped_games == 0:
                     warnings.warn(f"SelfPlay: more than {self.max_finished_kept} finished games are waiting; call "
                                   "drain_finished() -- further games are dropped (dropped_games counts them)")
                 self.dropped_games += 1
                 continue
+            keep.append((s, start, 1 if winner[s] == 1 else (-1 if winner[s] == 2 else 0), ids[s]))
+        if self.packed_records:
+            packed = self._pack_from_log(keep) if keep else None
+            if packed is not None:
+                self.finished_packed.append(packed)
+                self._packed_waiting += len(packed["game_val"])
+            return
+        for s, start, vw, gid in keep:
             plies = [self.ply_record(e, s) for e in self._log if e["ply"] >= start and e["moved"][s]]
             if plies:
-                vw = 1 if winner[s] == 1 else (-1 if winner[s] == 2 else 0)
-                self.finished_games.append((vw, plies, ids[s]))
+                self.finished_games.append((vw, plies, gid))
+
+    @staticmethod
+    def _entry_csr(e):
+        """The visit policies of one logged ply (all game slots) as CSR, computed once per ply."""
+        if "csr" not in e:
+            from .records import _csr
+            e["csr"] = _csr(e["policy"])
+        return e["csr"]
+
+    def _pack_from_log(self, keep):
+        """The games in `keep` as one packed batch (records.pack_games' arrays; rows grouped by game, plies ascending) --
+        the same rows ply_record would cut out one by one, gathered per logged ply with array operations."""
+        import numpy as np
+        S = np.asarray([k[0] for k in keep], dtype=np.int64)
+        start = np.asarray([k[1] for k in keep], dtype=np.int64)
+        feat, hist, meta, cnt, pidx, pval, gk, ply = [], [], [], [], [], [], [], []
+        for e in self._log:
+            k = np.flatnonzero(np.asarray(e["moved"])[S] & (e["ply"] >= start))
+            if k.size == 0:
+                continue
+            sl = S[k]
+            b = e["boards"]
+            turn = b[sl, 33].astype(np.int64)
+            persp = np.where(turn % 2 == 1, 0, 1)
+            hl = b[sl, 35].astype(np.int64)
+            hlen = np.where(persp == 0, hl & 15, hl >> 4)
+            feat.append(e["feat"][sl])
+            hist.append(e["hist"][sl, persp])
+            meta.append(np.stack([hlen, turn, persp], axis=1).astype(np.uint8))
+            ptr, idx, val = self._entry_csr(e)
+            c = ptr[sl + 1] - ptr[sl]
+            src = np.repeat(ptr[sl] - (np.cumsum(c) - c), c) + np.arange(int(c.sum()))
+            cnt.append(c)
+            pidx.append(idx[src])
+            pval.append(val[src])
+            gk.append(k)
+            ply.append(np.full(k.size, e["ply"], dtype=np.int64))
+        if not feat:
+            return None
+        gk, ply, cnt = np.concatenate(gk), np.concatenate(ply), np.concatenate(cnt)
+        order = np.lexsort((ply, gk))                           # rows by game, plies ascending
+        old_ptr = np.cumsum(cnt) - cnt
+        c = cnt[order]
+        new_ptr = np.zeros(len(c) + 1, dtype=np.int64)
+        np.cumsum(c, out=new_ptr[1:])
+        src = np.repeat(old_ptr[order] - new_ptr[:-1], c) + np.arange(int(new_ptr[-1]))
+        rows_per_game = np.bincount(gk, minlength=len(keep))
+        has = rows_per_game > 0                                 # a game without a logged row leaves no entry (as the row-wise path)
+        game_ptr = np.zeros(int(has.sum()) + 1, dtype=np.int64)
+        np.cumsum(rows_per_game[has], out=game_ptr[1:])
+        return {"feat": np.concatenate(feat)[order], "hist": np.concatenate(hist)[order], "meta": np.concatenate(meta)[order],
+                "pol_idx": np.concatenate(pidx)[src], "pol_val": np.concatenate(pval)[src], "pol_ptr": new_ptr,
+                "game_ptr": game_ptr, "game_val": np.asarray([k[2] for k in keep], dtype=np.int8)[has],
+                "game_id": np.asarray([k[3] for k in keep], dtype=np.int64)[has]}
 
     def drain_finished(self):
         """Take (and forget) every finished game collected so far: list of (value_white, plies, game_id);
         `game_rows(entry)` turns one into the reference's rows."""
         out, self.finished_games = self.finished_games, []
         return out
+
+    def drain_finished_packed(self):
+        """packed_records=True: take (and forget) the finished games collected so far as ONE packed batch
+        (records.pack_games' arrays; records.unpack_game / PackedGames expand them), or None if there are none."""
+        from . import records
+        batches, self.finished_packed, self._packed_waiting = self.finished_packed, [], 0
+        return records.concat_packed(batches) if batches else None
 
     @staticmethod
     def ply_record(entry, g):
@@ -370,6 +444,7 @@ class SelfPlay:
             src = {"feat": feat, "policy": policy, "boards": boards, "hist": hist, "moved": moved}
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(self.device))
+            prev_copy = self._copy_done
             host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in src.items()}
             with torch.cuda.stream(self._copy_stream):
                 self._copy_stream.wait_event(ready)
@@ -390,6 +465,11 @@ class SelfPlay:
             oldest = min(self._start_ply)
             while self._log and self._log[0]["ply"] < oldest:
                 self._log.pop(0)
+            if self.packed_records and len(self._log) >= 2 and prev_copy is not None:
+                # the previous ply's copy was issued a whole search ago: its sparse policies are built now, while the GPU
+                # runs this ply's search (the host has nothing else to do), not when a thousand games end at once
+                prev_copy.synchronize()
+                self._entry_csr(self._log[-2])
         if forced is not None:
             forced = torch.as_tensor(forced, dtype=torch.int32, device=self.device)
             action = torch.where((forced >= -1) & (action != -2), forced, action)

@@ -97,47 +97,146 @@ def rows_from_game(entry):
     return game_entries(expanded, entry[0])
 
 
-def save_games(path, games):
-    """Finished games (SelfPlay.finished_games / drain_finished entries) -> one compressed .npz, ~1.5 KB per row."""
-    feat, hist, meta, pol_idx, pol_val, pol_ptr, game_ptr, game_val, game_id = [], [], [], [], [], [0], [0], [], []
+PACKED_KEYS = ("feat", "hist", "meta", "pol_idx", "pol_val", "pol_ptr", "game_ptr", "game_val", "game_id")
+
+
+def pack_games(games):
+    """Finished games (value_white, plies[, game id]) -> the arrays a play_<ts>.npz holds (and the form SelfPlayWorker's
+    children send): feat u64[R,144], hist u32[R,4,2,6], meta u8[R,3] = (valid history entries, turn, mover), the visit
+    policies as one CSR matrix (pol_ptr i64[R+1], pol_idx i16, pol_val f32), game_ptr i64[G+1] (rows of game g),
+    game_val i8[G], game_id i64[G] (-1 = unknown).  Rows are grouped by game, plies ascending."""
+    feat, hist, meta, pol, game_ptr, game_val, game_id = [], [], [], [], [0], [], []
     for entry in games:
         for words, hw, hlen, turn, policy, mover in entry[1]:
             feat.append(np.asarray(words, dtype=np.uint64).reshape(144))
             hist.append(np.asarray(hw, dtype=np.uint32).reshape(4, 2, 6))
             meta.append((int(hlen), int(turn), int(mover)))
-            nz = np.flatnonzero(policy)
-            pol_idx.append(nz.astype(np.int16))
-            pol_val.append(np.asarray(policy, dtype=np.float32)[nz])
-            pol_ptr.append(pol_ptr[-1] + len(nz))
+            pol.append(np.asarray(policy, dtype=np.float32).reshape(1584))
         game_ptr.append(len(feat))
         game_val.append(int(entry[0]))
         game_id.append(int(entry[2]) if len(entry) > 2 else -1)
-    np.savez_compressed(
-        path, feat=np.stack(feat) if feat else np.zeros((0, 144), np.uint64),
-        hist=np.stack(hist) if hist else np.zeros((0, 4, 2, 6), np.uint32), meta=np.asarray(meta, dtype=np.uint8).reshape(-1, 3),
-        pol_idx=np.concatenate(pol_idx) if pol_idx else np.zeros(0, np.int16),
-        pol_val=np.concatenate(pol_val) if pol_val else np.zeros(0, np.float32), pol_ptr=np.asarray(pol_ptr, dtype=np.int64),
-        game_ptr=np.asarray(game_ptr, dtype=np.int64), game_val=np.asarray(game_val, dtype=np.int8),
-        game_id=np.asarray(game_id, dtype=np.int64))
+    pol_ptr, pol_idx, pol_val = _csr(np.stack(pol) if pol else np.zeros((0, 1584), np.float32))
+    return {"feat": np.stack(feat) if feat else np.zeros((0, 144), np.uint64),
+            "hist": np.stack(hist) if hist else np.zeros((0, 4, 2, 6), np.uint32),
+            "meta": np.asarray(meta, dtype=np.uint8).reshape(-1, 3), "pol_idx": pol_idx, "pol_val": pol_val, "pol_ptr": pol_ptr,
+            "game_ptr": np.asarray(game_ptr, dtype=np.int64), "game_val": np.asarray(game_val, dtype=np.int8),
+            "game_id": np.asarray(game_id, dtype=np.int64)}
+
+
+def _csr(dense):
+    """float32 [R,1584] -> (ptr i64[R+1], column i16[N], value f32[N]) of the non-zero entries, columns ascending per row."""
+    r, c = np.nonzero(dense)
+    ptr = np.zeros(dense.shape[0] + 1, dtype=np.int64)
+    np.cumsum(np.bincount(r, minlength=dense.shape[0]), out=ptr[1:])
+    return ptr, c.astype(np.int16), dense[r, c].astype(np.float32)
+
+
+def packed_games(packed):
+    return len(packed["game_val"])
+
+
+def slice_packed(packed, lo, hi):
+    """Games lo .. hi-1 of a packed batch as a packed batch of their own."""
+    r0, r1 = int(packed["game_ptr"][lo]), int(packed["game_ptr"][hi])
+    p0, p1 = int(packed["pol_ptr"][r0]), int(packed["pol_ptr"][r1])
+    return {"feat": packed["feat"][r0:r1], "hist": packed["hist"][r0:r1], "meta": packed["meta"][r0:r1],
+            "pol_idx": packed["pol_idx"][p0:p1], "pol_val": packed["pol_val"][p0:p1],
+            "pol_ptr": packed["pol_ptr"][r0:r1 + 1] - p0, "game_ptr": packed["game_ptr"][lo:hi + 1] - r0,
+            "game_val": packed["game_val"][lo:hi], "game_id": packed["game_id"][lo:hi]}
+
+
+def concat_packed(batches):
+    """Several packed batches -> one (game order = batch order)."""
+    batches = list(batches)
+    if len(batches) == 1:
+        return batches[0]
+    if not batches:
+        return pack_games([])
+    out = {k: np.concatenate([b[k] for b in batches]) for k in ("feat", "hist", "meta", "pol_idx", "pol_val", "game_val", "game_id")}
+    for key, unit in (("pol_ptr", "pol_idx"), ("game_ptr", "meta")):
+        parts, base = [np.zeros(1, dtype=np.int64)], 0
+        for b in batches:
+            parts.append(b[key][1:] + base)
+            base += len(b[unit])
+        out[key] = np.concatenate(parts)
+    return out
+
+
+def unpack_game(packed, g):
+    """Game g of a packed batch as SelfPlay collects it: (value_white, plies, game id), plies =
+    (features uint64[144], history words uint32[4,2,6], valid entries, turn, dense policy float32[1584], mover)."""
+    pol_idx, pol_val, pol_ptr, meta = packed["pol_idx"], packed["pol_val"], packed["pol_ptr"], packed["meta"]
+    plies = []
+    for r in range(int(packed["game_ptr"][g]), int(packed["game_ptr"][g + 1])):
+        policy = np.zeros(1584, dtype=np.float32)
+        lo, hi = int(pol_ptr[r]), int(pol_ptr[r + 1])
+        policy[pol_idx[lo:hi]] = pol_val[lo:hi]
+        plies.append((packed["feat"][r], packed["hist"][r], int(meta[r, 0]), int(meta[r, 1]), policy, int(meta[r, 2])))
+    return (int(packed["game_val"][g]), plies, int(packed["game_id"][g]))
+
+
+class PackedGames:
+    """Read-only mapping game id -> (value_white, plies, game id) over packed batches; a game is expanded when it is asked
+    for (SelfPlayWorker.results in the compact format: 1024 finished games are 55 k dense 1584-wide policies otherwise)."""
+
+    def __init__(self):
+        self._where = {}
+
+    def add(self, packed):
+        for g, gid in enumerate(packed["game_id"].tolist()):
+            self._where[int(gid)] = (packed, g)
+
+    def sort(self):
+        self._where = dict(sorted(self._where.items()))
+
+    def __getitem__(self, gid):
+        packed, g = self._where[gid]
+        return unpack_game(packed, g)
+
+    def __iter__(self):
+        return iter(self._where)
+
+    def __len__(self):
+        return len(self._where)
+
+    def __contains__(self, gid):
+        return gid in self._where
+
+    def keys(self):
+        return self._where.keys()
+
+    def values(self):
+        return (self[k] for k in self._where)
+
+    def items(self):
+        return ((k, self[k]) for k in self._where)
+
+    def rows_of(self, gid):
+        """Number of rows (plies) of a game without expanding it."""
+        packed, g = self._where[gid]
+        return int(packed["game_ptr"][g + 1] - packed["game_ptr"][g])
+
+
+def save_packed(path, packed):
+    """One packed batch -> one compressed .npz, ~1.5 KB per row."""
+    np.savez_compressed(path, **{k: packed[k] for k in PACKED_KEYS})
     return path
+
+
+def save_games(path, games):
+    """Finished games (SelfPlay.finished_games / drain_finished entries) -> one compressed .npz."""
+    return save_packed(path, pack_games(games))
+
+
+def load_packed(path):
+    with np.load(path) as z:                      # plain arrays only: nothing in the file is executed
+        return {k: z[k] for k in PACKED_KEYS}
 
 
 def load_games(path):
     """Inverse of save_games: list of (value_white, plies, game id) with plies as SelfPlay.ply_record builds them."""
-    with np.load(path) as z:                      # plain arrays only: nothing in the file is executed
-        feat, hist, meta = z["feat"], z["hist"], z["meta"]
-        pol_idx, pol_val, pol_ptr = z["pol_idx"], z["pol_val"], z["pol_ptr"]
-        game_ptr, game_val, game_id = z["game_ptr"], z["game_val"], z["game_id"]
-    games = []
-    for g in range(len(game_val)):
-        plies = []
-        for r in range(int(game_ptr[g]), int(game_ptr[g + 1])):
-            policy = np.zeros(1584, dtype=np.float32)
-            lo, hi = int(pol_ptr[r]), int(pol_ptr[r + 1])
-            policy[pol_idx[lo:hi]] = pol_val[lo:hi]
-            plies.append((feat[r], hist[r], int(meta[r, 0]), int(meta[r, 1]), policy, int(meta[r, 2])))
-        games.append((int(game_val[g]), plies, int(game_id[g])))
-    return games
+    packed = load_packed(path)
+    return [unpack_game(packed, g) for g in range(packed_games(packed))]
 
 
 def dataset_from_games(games):

@@ -72,15 +72,23 @@ def _game_worker(rank, world, cfg, out):
         ids = game_id_stream(rank, world, cfg["total_games"])
         # games that start in lock step mostly end on the same ply (the 55-turn cap): every slot's game can be waiting in
         # finished_games at once, so the keep limit must cover the whole batch (this loop drains after every ply)
+        compact = cfg["row_format"] == "compact"
         sp = mcts.SelfPlay(cfg["games_per_gpu"], cfg["sims"], evaluator, device=0, slots=cfg["slots"], seed=cfg["seed"],
-                           game_ids=ids, max_finished_kept=max(1024, 2 * cfg["games_per_gpu"]))
+                           game_ids=ids, max_finished_kept=max(1024, 2 * cfg["games_per_gpu"]), packed_records=compact)
         out.put(("ready", rank, time.time(), 0, None))
         while True:
             sp.play_ply()
-            for entry in sp.drain_finished():
-                # "json": the reference's rows (lists of 8,064 numbers per row: fine for a few hundred games); "compact": the
-                # game as it left the GPU (packed features, sparse policy), expanded only when somebody asks
-                out.put(("game", rank, entry[2], entry[0], mcts.SelfPlay.game_rows(entry) if cfg["row_format"] == "json" else entry))
+            if compact:
+                # the games as they left the GPU (packed features, sparse policies), every game that ended on this ply in
+                # ONE message of arrays: a thousand lock-step games ending together are 55 k rows -- 430 MB to pickle as
+                # per-row tuples with dense policies, 80 MB like this
+                packed = sp.drain_finished_packed()
+                if packed is not None:
+                    out.put(("games", rank, packed))
+            else:
+                for entry in sp.drain_finished():
+                    # the reference's rows (lists of 8,064 numbers per row: fine for a few hundred games)
+                    out.put(("game", rank, entry[2], entry[0], mcts.SelfPlay.game_rows(entry)))
             if sp.running() == 0:
                 break
         illegal, leaves = sp.env.illegal_count(), sp.leaf_histogram()
@@ -112,9 +120,10 @@ class SelfPlayWorker:
             raise RuntimeError("SelfPlayWorker: no GPU given / visible (there is no CPU path)")
         self.datapath, self.games_per_file, self.report_every = datapath, games_per_file, report_every
         self._worker, self._log = worker, log
-        self.results = {}            # game id -> (value_white, rows)
+        self.results = {}            # game id -> (value_white, rows); compact: records.PackedGames (a game expands when asked for)
         self.win_lose, self.game_lens, self.files = [], [], []
         self.buffer = []
+        self._writers, self._pending_files = None, []
         self.leaf_kinds = {}         # leaves of every simulation by kind, summed over the ranks (mcts.LEAF_KINDS)
         self.ready_at = {}           # rank -> wall-clock time its engine was built (network on the GPU, trees allocated)
 
@@ -133,14 +142,16 @@ class SelfPlayWorker:
         return procs
 
     def _take(self, game_id, value_white, rows):
-        compact = self.row_format == "compact"
-        self.results[game_id] = rows if compact else (value_white, rows)        # compact: the whole (value, plies, id) entry
+        if self.row_format == "compact":          # a child that sends one whole (value, plies, id) entry per message
+            from . import records
+            return self._take_packed(records.pack_games([rows]))
+        self.results[game_id] = (value_white, rows)
         self.win_lose.append(value_white)
-        self.game_lens.append(len(rows[1]) if compact else len(rows))
-        if compact:
-            self.buffer.append(rows)
-        else:
-            self.buffer += rows
+        self.game_lens.append(len(rows))
+        self.buffer += rows
+        self._after_game()
+
+    def _after_game(self):
         n = len(self.win_lose)
         if self.games_per_file and n % self.games_per_file == 0:
             self.flush_buffer()
@@ -149,17 +160,47 @@ class SelfPlayWorker:
             self._log(f" Total_game {n} ---  Mean_game_len {sum(self.game_lens) / n:.2f} ---  "
                       f"White_Win % {wins / n:.2f} --- ")
 
+    def _take_packed(self, packed):
+        """A packed batch of finished games (records.pack_games' arrays) from a child."""
+        from . import records
+        if not isinstance(self.results, records.PackedGames):
+            self.results = records.PackedGames()
+        self.results.add(packed)
+        lens = (packed["game_ptr"][1:] - packed["game_ptr"][:-1]).tolist()
+        for g, vw in enumerate(packed["game_val"].tolist()):
+            self.win_lose.append(vw)
+            self.game_lens.append(lens[g])
+            self.buffer.append(records.slice_packed(packed, g, g + 1))      # (views: files are cut at exactly games_per_file)
+            self._after_game()
+
     def flush_buffer(self):
         from . import records
         if self.buffer and self.datapath:
             if self.row_format == "compact":
                 import datetime
+                from concurrent.futures import ThreadPoolExecutor
                 os.makedirs(self.datapath, exist_ok=True)
                 name = "play_%s.npz" % datetime.datetime.now().strftime("%Y%m%d-%H%M%S.%f")
-                self.files.append(records.save_games(os.path.join(self.datapath, name), self.buffer))
+                path = os.path.join(self.datapath, name)
+                # compression (zlib, outside the GIL) runs on writer threads while the parent goes on receiving games;
+                # start() / wait_files() joins them
+                if self._writers is None:
+                    self._writers = ThreadPoolExecutor(max_workers=4)
+                batch = self.buffer
+                self._pending_files.append(self._writers.submit(lambda: records.save_packed(path, records.concat_packed(batch))))
+                self.files.append(path)
             else:
                 self.files.append(records.flush_buffer(self.buffer, self.datapath))
         self.buffer = []
+
+    def wait_files(self):
+        """Every file handed to the writer threads is on disk when this returns (errors of a writer surface here)."""
+        pending, self._pending_files = self._pending_files, []
+        for f in pending:
+            f.result()
+        if self._writers is not None:
+            self._writers.shutdown(wait=True)
+            self._writers = None
 
     def start(self, timeout_s=None):
         """Play games 0 .. total_games-1; returns {game id: (value_white, rows)} ordered by game id.  Raises if a rank
@@ -184,6 +225,8 @@ class SelfPlayWorker:
                     continue
                 if msg[0] == "game":
                     self._take(msg[2], msg[3], msg[4])
+                elif msg[0] == "games":
+                    self._take_packed(msg[2])
                 elif msg[0] == "ready":
                     self.ready_at[msg[1]] = msg[2]
                 elif msg[0] == "done":
@@ -197,6 +240,7 @@ class SelfPlayWorker:
                         lost[msg[1]] = extra
                 else:
                     raise RuntimeError(f"self-play rank {msg[1]} failed: {msg[2]}")
+            self.flush_buffer()               # the last file is compressed while the children shut their GPUs down
             ok = True
         finally:
             if not ok:
@@ -208,7 +252,11 @@ class SelfPlayWorker:
                 if p.is_alive():
                     p.terminate()
         self.flush_buffer()
-        self.results = dict(sorted(self.results.items()))
+        self.wait_files()
+        if isinstance(self.results, dict):
+            self.results = dict(sorted(self.results.items()))
+        else:
+            self.results.sort()
         missing = sorted(set(range(self.cfg["total_games"])) - set(self.results))
         if lost or missing:
             raise RuntimeError(f"SelfPlayWorker: games lost -- per rank {lost}, missing ids {missing[:16]}"

@@ -36,3 +36,28 @@ def worker(rank, world, cfg, out):
         rows[0][0].append(gpu)            # smuggle the device assignment out for the test
         out.put(("game", rank, g, vw, rows))
     out.put(("done", rank, len(ids), 0, {"root_evaluated": len(ids)}, lost))
+
+
+def fabricate_compact(seed, game_id):
+    """A compact entry (value_white, plies, game id) that is a pure function of (seed, game id)."""
+    import numpy as np
+    rng = np.random.default_rng(seed * 1_000_003 + game_id)
+    plies = []
+    for t in range(int(rng.integers(3, 9))):
+        pol = np.zeros(1584, np.float32)
+        k = int(rng.integers(1, 12))
+        pol[rng.choice(1584, k, replace=False)] = (rng.random(k) + 0.05).astype(np.float32)
+        plies.append((rng.integers(0, 2 ** 56, 144, dtype=np.uint64), rng.integers(0, 2 ** 28, (4, 2, 6), dtype=np.uint32),
+                      min(t, 4), t + 1, pol, t & 1))
+    return (int(rng.integers(-1, 2)), plies, game_id)
+
+
+def packed_worker(rank, world, cfg, out):
+    """Sends finished games the way the real compact child does: packed batches of several games per message."""
+    from hive_alphazero_amd import records
+    from hive_alphazero_amd.dist import game_id_stream
+    ids = list(game_id_stream(rank, world, cfg["total_games"]))
+    order = ids[::2] + ids[1::2]
+    for lo in range(0, len(order), 3):
+        out.put(("games", rank, records.pack_games([fabricate_compact(cfg["seed"], g) for g in order[lo:lo + 3]])))
+    out.put(("done", rank, len(ids), 0, {"root_evaluated": len(ids)}, {"dropped": 0, "unrecorded": 0}))

@@ -467,3 +467,44 @@ def test_skipping_unread_leaf_rows_does_not_change_the_search():
         print(f"slots {slots}: {launched1} rows launched, {run1} evaluated, histogram says {asked} were read; kinds {h1.tolist()}")
         assert int(h1[2]) <= run1 <= asked and run1 < launched1
     B.close()
+
+
+@pytest.mark.gpu
+def test_packed_records_equal_the_row_wise_records():
+    """SelfPlay(packed_records=True) builds the finished games as packed array batches straight from the per-ply host
+    copies (what SelfPlayWorker's children send); SelfPlay's row-wise path cuts the same games out one ply_record at a
+    time.  Same seed, same game ids, slots refilled from a longer id stream: every game must come out identical -- features,
+    history words, valid-history count, turn, mover, value, and the dense policy rebuilt from the sparse one."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd import mcts, records
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    torch.manual_seed(0)
+    inf = InferenceNet(ChessNet().cuda().eval(), dtype=torch.bfloat16, tune_gemms=False)
+    G, total = 48, 80
+    out = {}
+    for packed in (False, True):
+        sp = mcts.SelfPlay(G, 6, inf, seed=77, game_ids=iter(range(total)), packed_records=packed, max_finished_kept=4096)
+        got = []
+        for _ in range(130):
+            sp.play_ply()
+            if packed:
+                b = sp.drain_finished_packed()
+                if b is not None:
+                    got += [records.unpack_game(b, g) for g in range(records.packed_games(b))]
+            else:
+                got += sp.drain_finished()
+            if sp.running() == 0:
+                break
+        assert sp.running() == 0 and sp.dropped_games == 0 and sp.unrecorded_games == 0
+        assert sp.env.illegal_count() == 0
+        sp.close()
+        out[packed] = {g[2]: g for g in got}
+    assert sorted(out[False]) == sorted(out[True]) == list(range(total))
+    rows = 0
+    for gid, a in out[False].items():
+        b = out[True][gid]
+        assert a[0] == b[0] and len(a[1]) == len(b[1]) and len(a[1]) > 0
+        for x, y in zip(a[1], b[1]):
+            assert all(np.array_equal(np.asarray(u), np.asarray(v)) for u, v in zip(x, y)), gid
+        rows += len(a[1])
+    print(f"{total} games, {rows} rows: packed batches == row-wise records")

@@ -350,3 +350,78 @@ def test_bench_gpus_flag_starts_the_ranks_itself(monkeypatch):
     else:
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert r.returncode == 0 and line["n_gpus"] == 2
+
+
+def test_packed_game_batches_round_trip_slice_and_concat(tmp_path):
+    """records.pack_games / unpack_game / slice_packed / concat_packed / PackedGames: the array form of finished games that
+    SelfPlayWorker's children send and play_<ts>.npz holds.  Packing, cutting into per-game slices, concatenating in another
+    order and expanding again must give back every game exactly; an empty batch and a game with an all-zero policy row
+    (a forced pass) included."""
+    from hive_alphazero_amd import records
+    rng = np.random.default_rng(4)
+
+    def game(gid, plies):
+        rows = []
+        for t in range(plies):
+            pol = np.zeros(1584, np.float32)
+            k = int(rng.integers(0, 30))
+            pol[rng.choice(1584, k, replace=False)] = rng.random(k).astype(np.float32) + 0.01
+            rows.append((rng.integers(0, 2 ** 56, 144, dtype=np.uint64), rng.integers(0, 2 ** 28, (4, 2, 6), dtype=np.uint32),
+                         int(rng.integers(0, 5)), t + 1, pol, t & 1))
+        return (int(rng.integers(-1, 2)), rows, gid)
+
+    def same(a, b):
+        assert a[0] == b[0] and a[2] == b[2] and len(a[1]) == len(b[1])
+        for x, y in zip(a[1], b[1]):
+            assert all(np.array_equal(np.asarray(u), np.asarray(v)) for u, v in zip(x, y))
+
+    games = [game(7, 5), game(3, 1), game(11, 9), game(0, 4)]
+    packed = records.pack_games(games)
+    assert records.packed_games(packed) == 4 and packed["game_ptr"].tolist() == [0, 5, 6, 15, 19]
+    for g, entry in enumerate(games):
+        same(records.unpack_game(packed, g), entry)
+    parts = [records.slice_packed(packed, g, g + 1) for g in (2, 0, 3, 1)]
+    again = records.concat_packed(parts)
+    assert again["game_id"].tolist() == [11, 7, 0, 3] and again["pol_ptr"][-1] == len(again["pol_idx"]) == len(packed["pol_idx"])
+    for g, src in enumerate((2, 0, 3, 1)):
+        same(records.unpack_game(again, g), games[src])
+    same(records.unpack_game(records.slice_packed(packed, 1, 3), 1), games[2])
+    empty = records.pack_games([])
+    assert records.packed_games(empty) == 0 and records.packed_games(records.concat_packed([])) == 0
+    both = records.concat_packed([empty, packed, empty])
+    assert both["game_ptr"].tolist() == packed["game_ptr"].tolist()
+    path = records.save_packed(str(tmp_path / "g.npz"), again)
+    for a, b in zip(records.load_games(path), (games[2], games[0], games[3], games[1])):
+        same(a, b)
+    view = records.PackedGames()
+    view.add(records.slice_packed(packed, 0, 2))
+    view.add(records.slice_packed(packed, 2, 4))
+    view.sort()
+    assert list(view) == [0, 3, 7, 11] and len(view) == 4 and 7 in view and 5 not in view
+    assert view.rows_of(11) == 9
+    same(view[11], games[2])
+    assert [k for k, _ in view.items()] == [0, 3, 7, 11]
+
+
+def test_selfplay_worker_takes_packed_batches_from_two_ranks(tmp_path):
+    """The compact route at world size 2 without a GPU: children send packed batches of several games per message
+    (records.pack_games' arrays); the parent cuts files at exactly games_per_file games on writer threads, `results` is a
+    lazy game-id mapping, and files + mapping hold every game exactly as fabricated."""
+    import fake_selfplay_worker as fk
+    from hive_alphazero_amd import records
+    from hive_alphazero_amd.self_play import SelfPlayWorker
+    w = SelfPlayWorker(total_games=23, games_per_gpu=4, sims=1, gpus=[0, 1], seed=3, datapath=str(tmp_path), games_per_file=5,
+                       report_every=0, worker=fk.packed_worker, log=lambda *_: None, row_format="compact")
+    res = w.start(timeout_s=120)
+    assert isinstance(res, records.PackedGames) and list(res) == list(range(23))
+    assert len(w.files) == 5 and all(os.path.exists(f) for f in w.files)          # 4 x 5 games + the last 3
+    loaded = [g for f in w.files for g in records.load_games(f)]
+    assert [len(records.load_games(f)) for f in w.files] == [5, 5, 5, 5, 3]
+    assert sorted(g[2] for g in loaded) == list(range(23))
+    assert sum(w.game_lens) == sum(len(g[1]) for g in loaded) and len(w.win_lose) == 23
+    for entry in loaded:
+        want = fk.fabricate_compact(3, entry[2])
+        for got in (entry, res[entry[2]]):
+            assert got[0] == want[0] and len(got[1]) == len(want[1])
+            for x, y in zip(got[1], want[1]):
+                assert all(np.array_equal(np.asarray(u), np.asarray(v)) for u, v in zip(x, y))
