@@ -298,3 +298,58 @@ def dataset_tensors_gpu(games, device=None, dtype=None, layout="chw"):
     _lib.check(L.hive_expand_launch(p(tb), p(th), p(tf), n, p(planes), dt, _lib.CHW if layout == "chw" else _lib.HWC,
                                     ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     return planes, torch.from_numpy(policies).to(dev), torch.from_numpy(values).to(dev)
+
+
+def packed_values(packed):
+    """float32[R]: the training value of every row of a packed batch -- value_white from the mover's side (draw / length cap
+    = -1 for both, self_play.py:178-191), discounted by 0.99 ** (moves of that side still to come), optimize.py:42-65."""
+    gp = packed["game_ptr"]
+    n = int(gp[-1]) if len(gp) else 0
+    gi = np.repeat(np.arange(len(gp) - 1), np.diff(gp))
+    mover = packed["meta"][:, 2].astype(np.int64)
+    vw = packed["game_val"].astype(np.int64)[gi]
+    value = np.where(vw == 0, -1.0, np.where(mover == 0, vw, -vw).astype(np.float64))
+    left = np.zeros(n, dtype=np.int64)                        # moves of the row's side after this one
+    for side in (0, 1):
+        c = np.concatenate([[0], np.cumsum(mover == side)])
+        seen = c[1:] - c[gp[:-1]][gi]
+        total = (c[gp[1:]] - c[gp[:-1]])[gi]
+        left = np.where(mover == side, total - seen, left)
+    table = np.asarray([DISCOUNTED_REWARD ** k for k in range(int(left.max()) + 1 if n else 1)])
+    return np.where(left > 0, value * table[left], value).astype(np.float32)
+
+
+def dataset_tensors_gpu_packed(packed, device=None, dtype=None, layout="chw"):
+    """dataset_tensors_gpu for a packed batch (records.load_packed / SelfPlay.drain_finished_packed) without a Python
+    object per row: the packed features, history words and turn bytes go up as they are (1.5 KB per row), the env's plane
+    writer widens them (hive_expand_launch), the sparse policies are scattered into the dense matrix on the GPU."""
+    import ctypes
+    import torch
+    from . import _lib
+    L = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    dtype = dtype or torch.float32
+    n = len(packed["meta"])
+    shape = (n, 56, 12, 12) if layout == "chw" else (n, 12, 12, 56)
+    if n == 0:
+        return (torch.zeros(shape, dtype=dtype, device=dev), torch.zeros((0, 1584), dtype=torch.float32, device=dev),
+                torch.zeros((0,), dtype=torch.float32, device=dev))
+    meta = packed["meta"].astype(np.int64)
+    hlen, turn, mover = meta[:, 0], meta[:, 1], meta[:, 2]
+    boards = np.zeros((n, 64), dtype=np.uint8)
+    boards[:, 33] = turn
+    boards[:, 35] = np.where(mover == 0, hlen & 15, (hlen << 4) & 255)
+    hist = np.zeros((n, 2, 4, 2, 6), dtype=np.uint32)
+    hist[np.arange(n), mover] = packed["hist"]
+    planes = torch.empty(shape, dtype=dtype, device=dev)
+    tb, th = torch.from_numpy(boards).to(dev), torch.from_numpy(hist.view(np.uint8).reshape(n, 384)).to(dev)
+    tf = torch.from_numpy(np.ascontiguousarray(packed["feat"]).view(np.int64)).to(dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    dt = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}[dtype]
+    _lib.check(L.hive_expand_launch(p(tb), p(th), p(tf), n, p(planes), dt, _lib.CHW if layout == "chw" else _lib.HWC,
+                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(packed["pol_ptr"]))
+    flat = torch.from_numpy(rows * 1584 + packed["pol_idx"].astype(np.int64)).to(dev)
+    policies = torch.zeros((n * 1584,), dtype=torch.float32, device=dev)
+    policies[flat] = torch.from_numpy(np.ascontiguousarray(packed["pol_val"])).to(dev)
+    return planes, policies.view(n, 1584), torch.from_numpy(packed_values(packed)).to(dev)

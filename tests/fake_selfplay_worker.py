@@ -47,7 +47,7 @@ def fabricate_compact(seed, game_id):
         pol = np.zeros(1584, np.float32)
         k = int(rng.integers(1, 12))
         pol[rng.choice(1584, k, replace=False)] = (rng.random(k) + 0.05).astype(np.float32)
-        plies.append((rng.integers(0, 2 ** 56, 144, dtype=np.uint64), rng.integers(0, 2 ** 28, (4, 2, 6), dtype=np.uint32),
+        plies.append((rng.integers(0, 2 ** 56, 144, dtype=np.uint64), rng.integers(0, 2 ** 28, (4, 2, 6), dtype=np.uint32) & np.uint32(0x0FFF0FFF),
                       min(t, 4), t + 1, pol, t & 1))
     return (int(rng.integers(-1, 2)), plies, game_id)
 

@@ -522,6 +522,16 @@ def test_compact_games_widen_to_trainer_tensors_on_the_gpu():
         assert np.array_equal(hwc.float().cpu().numpy(), states)
         assert np.array_equal(chw.float().cpu().numpy(), states.transpose(0, 3, 1, 2))
         assert np.array_equal(pol.cpu().numpy(), policies) and np.allclose(val.cpu().numpy(), values, atol=1e-6)
+    # the packed form (what the children send and the files hold) widens without a Python object per row: same tensors
+    packed = records.pack_games(games)
+    assert np.array_equal(records.packed_values(packed), values)
+    for dtype, layout in ((torch.float32, "chw"), (torch.bfloat16, "hwc")):
+        a = records.dataset_tensors_gpu(games, dtype=dtype, layout=layout)
+        b = records.dataset_tensors_gpu_packed(packed, dtype=dtype, layout=layout)
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(a, b)), (dtype, layout)
+    empty = records.dataset_tensors_gpu_packed(records.pack_games([]))
+    assert empty[0].shape == (0, 56, 12, 12) and empty[1].shape == (0, 1584) and empty[2].shape == (0,)
 
 
 def test_finished_selfplay_games_replay_through_the_oracle(bf16_net):

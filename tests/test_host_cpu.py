@@ -366,7 +366,7 @@ def test_packed_game_batches_round_trip_slice_and_concat(tmp_path):
             pol = np.zeros(1584, np.float32)
             k = int(rng.integers(0, 30))
             pol[rng.choice(1584, k, replace=False)] = rng.random(k).astype(np.float32) + 0.01
-            rows.append((rng.integers(0, 2 ** 56, 144, dtype=np.uint64), rng.integers(0, 2 ** 28, (4, 2, 6), dtype=np.uint32),
+            rows.append((rng.integers(0, 2 ** 56, 144, dtype=np.uint64), rng.integers(0, 2 ** 28, (4, 2, 6), dtype=np.uint32) & np.uint32(0x0FFF0FFF),
                          int(rng.integers(0, 5)), t + 1, pol, t & 1))
         return (int(rng.integers(-1, 2)), rows, gid)
 
@@ -401,6 +401,8 @@ def test_packed_game_batches_round_trip_slice_and_concat(tmp_path):
     assert view.rows_of(11) == 9
     same(view[11], games[2])
     assert [k for k, _ in view.items()] == [0, 3, 7, 11]
+    # the trainer's values (optimize.py:42-65 discount) straight from the packed arrays == the row-wise rule
+    assert np.array_equal(records.packed_values(packed), records.dataset_from_games(games)[2])
 
 
 def test_selfplay_worker_takes_packed_batches_from_two_ranks(tmp_path):
