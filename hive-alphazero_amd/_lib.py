@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "hive_batch_size", "hive_batch_set_stream", "hive_batch_reset", "hive_batch_step",
     "hive_batch_illegal_count", "hive_batch_legal", "hive_batch_encode", "hive_batch_terminal",
     "hive_batch_export", "hive_batch_import", "hive_movegen_launch", "hive_encode_launch",
-    "hive_terminal_launch", "hive_step_launch", "hive_step_launch_counted", "hive_leaf_launch", "hive_expand_launch",
+    "hive_terminal_launch", "hive_step_launch", "hive_step_launch_counted", "hive_leaf_launch", "hive_expand_launch", "hive_leaf_dedup_launch",
     "hive_single_create", "hive_single_destroy", "hive_single_advance", "hive_single_encode",
     # include/hive_search.h
     "hive_search_create", "hive_search_destroy", "hive_search_set_stream", "hive_search_set_params",
@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "hive_search_leaf_need",
     # include/hive_nn.h
     "hive_nn_conv3x3", "hive_nn_resblock", "hive_nn_conv3x3_dt", "hive_nn_resblock_dt", "hive_nn_tower",
-    "hive_nn_conv3x3_sel", "hive_nn_resblock_sel",
+    "hive_nn_conv3x3_sel", "hive_nn_resblock_sel", "hive_nn_copy_rows",
     "hive_nn_bn_workspace_floats", "hive_nn_bn_act_fwd", "hive_nn_bn_act_bwd",
     "hive_nn_pack_conv3x3_weights", "hive_nn_conv3x3_wgrad", "hive_nn_wgrad_workspace_floats",
 ]
@@ -126,6 +126,8 @@ def load():
     L.hive_nn_conv3x3_sel.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]
     L.hive_nn_resblock_sel.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     L.hive_search_leaf_need.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.hive_nn_copy_rows.argtypes = [vp, vp, i32, ctypes.c_longlong, vp]
+    L.hive_leaf_dedup_launch.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
     f32, i64 = ctypes.c_float, ctypes.c_longlong
     L.hive_nn_bn_workspace_floats.restype = i32
     L.hive_nn_bn_act_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i64, i32, i32, vp]

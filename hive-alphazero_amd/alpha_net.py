@@ -496,9 +496,23 @@ class InferenceNet:
                                           ctypes.c_void_p(need.data_ptr()) if need is not None else None, st))
         return out
 
-    def _tower_hip(self, x_hwc, need=None):
+    def _tower_hip(self, x_hwc, need=None, rep=None):
         """need: int8[B] on the device or None -- boards flagged 0 are skipped by every kernel of the tower (their rows of
-        the activation buffers keep stale, finite values; the heads compute on them and nobody reads the result)."""
+        the activation buffers keep stale, finite values; the heads compute on them and nobody reads the result).
+        rep: int32[B] or None -- row i takes the tower output of row rep[i] (equal leaves, hive_leaf_dedup_launch)
+        before the heads run, i.e. exactly the activations it would have computed itself."""
+        out = self._tower_hip_rows(x_hwc, need)
+        if rep is not None:
+            import ctypes
+            from ._lib import check
+            nhwc = out.permute(0, 2, 3, 1)                   # the contiguous [B,12,12,256] buffer behind the NCHW view
+            assert nhwc.is_contiguous()
+            check(self._L.hive_nn_copy_rows(ctypes.c_void_p(nhwc.data_ptr()), ctypes.c_void_p(rep.data_ptr()), nhwc.shape[0],
+                                            144 * 256 * nhwc.element_size(),
+                                            ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return out
+
+    def _tower_hip_rows(self, x_hwc, need=None):
         B = x_hwc.shape[0]
         x_hwc = x_hwc.contiguous()
         if need is not None and (self.tower or not self.fuse_blocks):
@@ -563,10 +577,10 @@ class InferenceNet:
                 s, cur = s2, (cur + 2) % 3
         return s.permute(0, 3, 1, 2)             # NCHW view with channels-last strides
 
-    def _forward(self, x_hwc, need=None):
+    def _forward(self, x_hwc, need=None, rep=None):
         # x_hwc: [B,12,12,56] in self.dtype; viewed as NCHW with channels-last strides (zero copy)
         if self.conv == "hip":
-            s = self._tower_hip(x_hwc, need)
+            s = self._tower_hip(x_hwc, need, rep)
         else:
             x = x_hwc.permute(0, 3, 1, 2)
             s = F.relu(F.conv2d(x, self.stem[0], self.stem[1], padding=1))
@@ -606,26 +620,31 @@ class InferenceNet:
             tn.tuning_enable(False)
 
     accepts_need = True          # __call__ takes the row selection of hive_search_leaf_need (mcts.TreeSearch asks for this)
+    accepts_rep = True           # ... and the representatives of equal rows (hive_leaf_dedup_launch)
 
-    def __call__(self, planes_hwc, need=None):
+    def __call__(self, planes_hwc, need=None, rep=None):
         """need: int8[B] on the device (1 = this row's p / v will be read) or None = every row.  Rows flagged 0 come back
-        with unspecified (finite) numbers; the tower's kernels skip their boards (hive_nn_resblock_sel)."""
+        with unspecified (finite) numbers; the tower's kernels skip their boards (hive_nn_resblock_sel).
+        rep: int32[B] or None -- equal rows (hive_leaf_dedup_launch): row i, switched off in `need`, gets the tower output
+        of row rep[i] copied in before the heads, so its p / v are the bits it would have produced itself."""
         with self._lock:
-            p, v = self._call_locked(planes_hwc, need if self.conv == "hip" else None)
+            hip = self.conv == "hip"
+            p, v = self._call_locked(planes_hwc, need if hip else None, rep if hip else None)
             return (p.clone(), v.clone()) if self.use_graph else (p, v)
 
-    def _call_locked(self, planes_hwc, need=None):
+    def _call_locked(self, planes_hwc, need=None, rep=None):
         B = planes_hwc.shape[0]
         if planes_hwc.dtype != self.dtype:
             planes_hwc = planes_hwc.to(self.dtype)
         if not self.use_graph:
-            return self._forward(planes_hwc, need)
+            return self._forward(planes_hwc, need, rep)
         hip = self.conv == "hip"
         g = self._graphs.get(B)
         if g is None:
             static_in = torch.zeros_like(planes_hwc)
             static_in.copy_(planes_hwc)
             static_need = torch.ones((B,), dtype=torch.int8, device=self.device) if hip else None
+            static_rep = torch.arange(B, dtype=torch.int32, device=self.device) if hip else None
             try:
                 s = torch.cuda.Stream(self.device)
                 s.wait_stream(torch.cuda.current_stream(self.device))
@@ -633,14 +652,14 @@ class InferenceNet:
                     if self.tune_gemms and B >= 256:
                         self._tune(static_in)
                     for _ in range(2):
-                        self._forward(static_in, static_need)
+                        self._forward(static_in, static_need, static_rep)
                 torch.cuda.current_stream(self.device).wait_stream(s)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    out = self._forward(static_in, static_need)
+                    out = self._forward(static_in, static_need, static_rep)
                 if hip:
                     graph.replay()             # every board selected: the graph's activation buffers now hold finite rows
-                g = [graph, static_in, out, static_need, True]
+                g = [graph, static_in, out, static_need, True, static_rep, True]
                 self._graphs[B] = g
             finally:
                 if self._tunable_before is not None:
@@ -650,7 +669,7 @@ class InferenceNet:
                     import torch.cuda.tunable as tn
                     tn.enable(self._tunable_before)
                     self._tunable_before = None
-        graph, static_in, out, static_need, all_rows = g
+        graph, static_in, out, static_need, all_rows, static_rep, identity = g
         static_in.copy_(planes_hwc)
         if need is not None:
             static_need.copy_(need)
@@ -658,5 +677,11 @@ class InferenceNet:
         elif not all_rows:
             static_need.fill_(1)
             g[4] = True
+        if rep is not None:
+            static_rep.copy_(rep)
+            g[6] = False
+        elif not identity:
+            static_rep.copy_(torch.arange(B, dtype=torch.int32, device=self.device))
+            g[6] = True
         graph.replay()
         return out

@@ -893,6 +893,92 @@ __global__ void hive_tables_kernel(uint32_t *line, uint8_t *nbr)
     if (i < kCells * 8) nbr[i] = (&d_tables.nbr[0][0])[i];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// hive_leaf_dedup_launch: equal leaves of one batch.  The planes are a function of (HiveBoard, HiveHistory) alone, so two
+// rows with the same 448 bytes get the same prediction: lock-step games from the opening position ask the network about the
+// same few positions a thousand times (plies 0-2: 97 / 90 / 48 % of the rows, tools/leaf_dups.py).
+//   leaf_key_kernel    one wave per row: a 64-bit mix of the row's 56 eight-byte words
+//   leaf_dedup_kernel  ONE workgroup: an open-addressing table of the keys in LDS; every needed row finds its key's slot and
+//                      takes the minimum row index stored there as its representative (atomicMin: the outcome does not
+//                      depend on the order the threads arrive in), then compares its 448 bytes with the representative's --
+//                      a hash collision keeps the row as its own representative.
+constexpr int kDedupMaxRows = 4096, kDedupSlots = 8192;
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+
+__global__ void __launch_bounds__(256)
+leaf_key_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restrict__ hist, int n,
+                unsigned long long *__restrict__ keys)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    unsigned long long v = 0ull;
+    if (lane < 8) v = reinterpret_cast<const unsigned long long *>(boards + row)[lane];
+    else if (lane < 56) v = reinterpret_cast<const unsigned long long *>(hist + row)[lane - 8];
+    unsigned long long h = mix64(v + 0x9e3779b97f4a7c15ull * (unsigned long long)(lane + 1));
+    HIVE_UNROLL for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d, 64);       // lanes >= 56 add a constant
+    h = mix64(h);
+    if (lane == 0) keys[row] = h ? h : 1ull;                                       // 0 marks an empty table slot
+}
+
+__global__ void __launch_bounds__(1024)
+leaf_dedup_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__restrict__ hist, int n,
+                  const unsigned long long *__restrict__ keys, int8_t *__restrict__ need, int32_t *__restrict__ rep,
+                  unsigned long long *__restrict__ total)
+{
+    __shared__ unsigned long long tkey[kDedupSlots];
+    __shared__ int tmin[kDedupSlots];
+    __shared__ int dropped;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kDedupSlots; i += 1024) { tkey[i] = 0ull; tmin[i] = 0x7fffffff; }
+    if (tid == 0) dropped = 0;
+    __syncthreads();
+    int slot_of[kDedupMaxRows / 1024];
+    HIVE_UNROLL for (int j = 0; j < kDedupMaxRows / 1024; ++j) {
+        const int i = tid + j * 1024;
+        slot_of[j] = -1;
+        if (i < n && need[i]) {
+            const unsigned long long k = keys[i];
+            unsigned slot = (unsigned)(k >> 20) & (kDedupSlots - 1);
+            for (int probe = 0; probe < kDedupSlots; ++probe) {                    // at most 4096 keys in 8192 slots: ends
+                const unsigned long long prev = atomicCAS(&tkey[slot], 0ull, k);
+                if (prev == 0ull || prev == k) { atomicMin(&tmin[slot], i); slot_of[j] = (int)slot; break; }
+                slot = (slot + 1u) & (kDedupSlots - 1);
+            }
+        }
+    }
+    __syncthreads();
+    int mine = 0;
+    HIVE_UNROLL for (int j = 0; j < kDedupMaxRows / 1024; ++j) {
+        const int i = tid + j * 1024;
+        if (i >= n) continue;
+        int r = i;
+        if (slot_of[j] >= 0) {
+            const int first = tmin[slot_of[j]];
+            if (first != i) {
+                const unsigned long long *a = reinterpret_cast<const unsigned long long *>(boards + i);
+                const unsigned long long *b = reinterpret_cast<const unsigned long long *>(boards + first);
+                const unsigned long long *c = reinterpret_cast<const unsigned long long *>(hist + i);
+                const unsigned long long *d = reinterpret_cast<const unsigned long long *>(hist + first);
+                unsigned long long diff = 0ull;
+                for (int w = 0; w < (int)(sizeof(HiveBoard) / 8); ++w) diff |= a[w] ^ b[w];
+                for (int w = 0; w < (int)(sizeof(HiveHistory) / 8); ++w) diff |= c[w] ^ d[w];
+                if (diff == 0ull) { r = first; need[i] = 0; ++mine; }
+            }
+        }
+        rep[i] = r;
+    }
+    if (mine) atomicAdd(&dropped, mine);
+    __syncthreads();
+    if (tid == 0 && total && dropped) atomicAdd(total, 0ull - (unsigned long long)dropped);
+}
+
 }  // namespace hive
 
 // ====================================================================== host side / C ABI
@@ -1054,6 +1140,20 @@ int hive_leaf_launch(const HiveBoard *boards, const HiveHistory *hist, int n, vo
                            (hipStream_t)stream, mask, count);
     if (rc != HIVE_OK) return rc;
     if (over != nullptr || winner != nullptr) return hive_terminal_launch(boards, n, over, winner, stream);
+    return HIVE_OK;
+}
+
+int hive_leaf_dedup_launch(const HiveBoard *boards, const HiveHistory *hist, int n, int8_t *need, int32_t *rep,
+                           uint64_t *keys, uint64_t *total, void *stream)
+{
+    static_assert(sizeof(HiveBoard) == 64 && sizeof(HiveHistory) == 384, "leaf_key_kernel reads 8 + 48 eight-byte words");
+    if (n <= 0 || n > kDedupMaxRows || boards == nullptr || hist == nullptr || need == nullptr || rep == nullptr || keys == nullptr)
+        return fail(HIVE_E_ARG, "hive_leaf_dedup_launch: bad argument (1 <= n <= 4096)");
+    hipLaunchKernelGGL(leaf_key_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, boards, hist, n,
+                       reinterpret_cast<unsigned long long *>(keys));
+    hipLaunchKernelGGL(leaf_dedup_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, boards, hist, n,
+                       reinterpret_cast<const unsigned long long *>(keys), need, rep, reinterpret_cast<unsigned long long *>(total));
+    HIP_TRY(hipGetLastError());
     return HIVE_OK;
 }
 

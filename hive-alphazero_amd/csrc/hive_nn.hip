@@ -483,6 +483,19 @@ tower_kernel(const typename E::T *__restrict__ X, const typename E::T *__restric
     }
 }
 
+
+// rows of equal leaves (hive_leaf_dedup_launch): row i takes the bytes of row rep[i] (a representative, rep[r] == r, is
+// never written, so the copy is safe in place)
+__global__ void __launch_bounds__(256)
+copy_rows_kernel(uint4 *__restrict__ y, const int32_t *__restrict__ rep, int row16)
+{
+    const int i = blockIdx.x, r = rep[i];
+    if (r == i) return;
+    const uint4 *src = y + (size_t)r * row16;
+    uint4 *dst = y + (size_t)i * row16;
+    for (int k = threadIdx.x; k < row16; k += 256) dst[k] = src[k];
+}
+
 template <typename E>
 static int launch_conv(const void *x, int cin, const void *w, const float *bias, const void *residual, void *y, int batch,
                        int relu, const int8_t *need, hipStream_t s)
@@ -554,6 +567,17 @@ extern "C" int hive_nn_resblock_dt(const void *x, const void *w1, const float *b
                                    int batch, int dtype, void *stream)
 {
     return hive_nn_resblock_sel(x, w1, b1, w2, b2, y, batch, dtype, nullptr, stream);
+}
+
+extern "C" int hive_nn_copy_rows(void *y, const int32_t *rep, int batch, long long row_bytes, void *stream)
+{
+    if (!y || !rep || batch <= 0 || row_bytes <= 0 || (row_bytes & 15) || row_bytes > (1ll << 30) || ((uintptr_t)y & 15))
+        return set_error(HIVE_E_ARG, "hive_nn_copy_rows: bad argument (rows of a multiple of 16 bytes, 16-byte aligned)");
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, (uint4 *)y, rep,
+                       (int)(row_bytes / 16));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(HIVE_E_DEVICE, std::string("hive_nn_copy_rows: ") + hipGetErrorString(e));
+    return HIVE_OK;
 }
 
 extern "C" int hive_nn_resblock(const void *x, const void *w1, const float *b1, const void *w2, const float *b2, void *y,

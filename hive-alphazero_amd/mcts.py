@@ -37,7 +37,7 @@ class TreeSearch:
 
     def __init__(self, games, sims, evaluator, device=None, slots=1, seed=0, plane_dtype=None,
                  c_puct=0.7, noise_eps=0.25, dirichlet_alpha=0.3, max_nodes=None, transpositions=True, mode=PUCT,
-                 virtual_loss=None, max_game_length=None, skip_unread_rows=True):
+                 virtual_loss=None, max_game_length=None, skip_unread_rows=True, share_equal_leaves=True):
         """mode = PUCT: woker/solo_play.py::HivePlayer; mode = UCT: alpha_zero/MCTS_chess.py::UCT_search (plain tree, no
         noise, no length cap; with one slot the virtual loss is 0 so that W sums exactly like the sequential reference)."""
         L = load()
@@ -87,6 +87,12 @@ class TreeSearch:
         self.leaf_need = torch.ones((n,), dtype=torch.int8, device=dev)
         self.evals_run = torch.zeros((1,), dtype=torch.int64, device=dev)
         self.evals_launched = 0
+        # equal leaves of one batch (same board record and history = same planes) are evaluated once: lock-step games from
+        # the opening ask about the same few positions (hive_leaf_dedup_launch; batches of up to 4096 rows)
+        self.share_equal_leaves = (self.skip_unread_rows and bool(share_equal_leaves) and n <= 4096
+                                   and bool(getattr(evaluator, "accepts_rep", False)))
+        self.leaf_rep = torch.arange(n, dtype=torch.int32, device=dev)
+        self.leaf_keys = torch.zeros((n,), dtype=torch.int64, device=dev)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -124,7 +130,12 @@ class TreeSearch:
             if self.skip_unread_rows:
                 check(L.hive_search_leaf_need(self._h, k, _p(self.leaf_boards), _p(self.leaf_over), _p(self.leaf_need),
                                               _p(self.evals_run)))
-                p, v = self.evaluator(self.planes[:n], need=self.leaf_need[:n])
+                if self.share_equal_leaves:
+                    check(L.hive_leaf_dedup_launch(_p(self.leaf_boards), _p(self.leaf_hist), n, _p(self.leaf_need),
+                                                   _p(self.leaf_rep), _p(self.leaf_keys), _p(self.evals_run), s))
+                    p, v = self.evaluator(self.planes[:n], need=self.leaf_need[:n], rep=self.leaf_rep[:n])
+                else:
+                    p, v = self.evaluator(self.planes[:n], need=self.leaf_need[:n])
             else:
                 p, v = self.evaluator(self.planes[:n])
             self.evals_launched += n
@@ -194,13 +205,15 @@ class SelfPlay:
     `drain_finished_packed()`; what SelfPlayWorker's children send to the parent."""
 
     def __init__(self, games, sims, evaluator, device=None, slots=1, seed=0, plane_dtype=None,
-                 keep_records=True, game_ids=None, max_finished_kept=1024, report_every=0, log=print, packed_records=False):
+                 keep_records=True, game_ids=None, max_finished_kept=1024, report_every=0, log=print, packed_records=False,
+                 search_options=None):
         import itertools
         from .batch import BoardBatch
         self.games, self.sims = games, sims
         self.env = BoardBatch(games, device)
         self.device = self.env.device
-        self.search = TreeSearch(games, sims, evaluator, self.device.index, slots, seed, plane_dtype)
+        self.search = TreeSearch(games, sims, evaluator, self.device.index, slots, seed, plane_dtype,
+                                 **(search_options or {}))      # e.g. skip_unread_rows / share_equal_leaves = False
         self.keep_records = keep_records
         self.finished = 0
         self.white_wins = self.black_wins = self.draws = 0

@@ -170,6 +170,16 @@ int hive_leaf_launch(const HiveBoard *boards, const HiveHistory *hist, int n, vo
                      HiveLayout layout, void *workspace, uint32_t *mask, int32_t *count, int8_t *over, int8_t *winner,
                      void *stream);
 
+/* Equal leaves of one batch (n <= 4096 rows): a row with need != 0 whose (HiveBoard, HiveHistory) bytes equal those of
+ * an EARLIER needed row gets need = 0 and rep = that row's index; every other row gets rep = its own index.  The planes --
+ * and so the network's answer -- are a function of those 448 bytes alone, so the evaluator runs the representative only
+ * and the duplicates take its result (hive_nn_copy_rows).  The reference evaluates one position at a time
+ * (api_hive.py:62-69 behind solo_play.py:188-197); a thousand lock-step games from the opening ask about the same few
+ * positions.  keys = uint64[n] scratch; total (may be NULL): the number of rows switched off is SUBTRACTED from it
+ * (the counter hive_search_leaf_need added to). */
+int hive_leaf_dedup_launch(const HiveBoard *boards, const HiveHistory *hist, int n, int8_t *need, int32_t *rep,
+                           uint64_t *keys, uint64_t *total, void *stream);
+
 /* ---- One position, HOST buffers: the single-game surface of GamePlay without a round trip per question.
  * A HiveSingle owns a stream, a device block and a pinned host mirror; a call copies the position in, runs its kernels
  * as one launch chain, copies the answers out and synchronises once.  Not thread-safe; distinct handles are independent

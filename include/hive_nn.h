@@ -51,6 +51,11 @@ int hive_nn_conv3x3_sel(const void *x, int cin, const void *w, const float *bias
 int hive_nn_resblock_sel(const void *x, const void *w1, const float *b1, const void *w2, const float *b2, void *y,
                          int batch, int dtype, const int8_t *need, void *stream);
 
+/* Rows of equal leaves: row i of y ([batch] rows of row_bytes bytes, a multiple of 16) takes the bytes of row rep[i];
+ * rep[i] == i leaves the row alone.  rep comes from hive_leaf_dedup_launch (a representative always maps to itself).
+ * Run on the tower's output before the heads, it gives a duplicate exactly the activations it would have computed. */
+int hive_nn_copy_rows(void *y, const int32_t *rep, int batch, long long row_bytes, void *stream);
+
 /* The whole residual tower (alpha_net.py:87-99, the loop over res_0 .. res_{nblocks-1}) in ONE launch:
  *   x, y   [batch][144][256] channels-last (dtype as above); y must not alias x
  *   w      [2 * nblocks][9][8][16][64][8]: the fragment-major weights of conv1, conv2 of block 0, conv1 of block 1, ...

@@ -397,3 +397,50 @@ def test_planes_writer_streaming_launch_equals_small_launches(hv):
             assert torch.equal(big.view(torch.int16 if tdt == torch.bfloat16 else torch.int32),
                                small.view(torch.int16 if tdt == torch.bfloat16 else torch.int32)), (dt, ly)
             assert bool(torch.isfinite(big.float()).all())
+
+
+@pytest.mark.gpu
+def test_leaf_dedup_picks_the_first_equal_row():
+    """hive_leaf_dedup_launch against a dictionary on the host: random 448-byte rows with planted copies (also copies that
+    differ in ONE byte of the board or of the history, and copies of rows that are not needed), random need flags, several
+    batch sizes up to the 4096-row limit.  A needed row equal to an earlier needed row must be switched off and point at the
+    FIRST such row; everything else keeps need and points at itself; the counter loses exactly the rows switched off."""
+    assert torch.cuda.is_available()
+    import ctypes
+    from hive_alphazero_amd import _lib
+    L = _lib.load()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    rng = np.random.default_rng(8)
+    for n in (1, 5, 1024, 3000, 4096):
+        distinct = max(1, n // 7)
+        src = rng.integers(0, distinct, n)
+        base_b = rng.integers(0, 256, (distinct, 64), dtype=np.uint8)
+        base_h = rng.integers(0, 256, (distinct, 384), dtype=np.uint8)
+        boards, hist = base_b[src].copy(), base_h[src].copy()
+        for i in rng.choice(n, n // 10, replace=False):          # near copies: one byte off
+            if i % 2:
+                boards[i, rng.integers(0, 64)] ^= 1 << int(rng.integers(0, 8))
+            else:
+                hist[i, rng.integers(0, 384)] ^= 1 << int(rng.integers(0, 8))
+        need = (rng.random(n) < 0.8).astype(np.int8)
+        first, want_rep, want_need = {}, np.arange(n, dtype=np.int32), need.copy()
+        for i in range(n):
+            if not need[i]:
+                continue
+            key = boards[i].tobytes() + hist[i].tobytes()
+            if key in first:
+                want_rep[i], want_need[i] = first[key], 0
+            else:
+                first[key] = i
+        tb, th = torch.from_numpy(boards).cuda(), torch.from_numpy(hist).cuda()
+        tn = torch.from_numpy(need).cuda()
+        rep = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        keys = torch.zeros((n,), dtype=torch.int64, device="cuda")
+        total = torch.tensor([int(need.sum())], dtype=torch.int64, device="cuda")
+        _lib.check(L.hive_leaf_dedup_launch(P(tb), P(th), n, P(tn), P(rep), P(keys), P(total), None))
+        torch.cuda.synchronize()
+        assert np.array_equal(rep.cpu().numpy(), want_rep), n
+        assert np.array_equal(tn.cpu().numpy(), want_need), n
+        assert int(total.item()) == int(want_need.sum())
+    assert L.hive_leaf_dedup_launch(P(tb), P(th), 4097, P(tn), P(rep), P(keys), None, None) != 0      # over the row limit
+    assert L.hive_leaf_dedup_launch(P(tb), P(th), 8, None, P(rep), P(keys), None, None) != 0

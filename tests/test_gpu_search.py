@@ -452,7 +452,7 @@ def test_skipping_unread_leaf_rows_does_not_change_the_search():
     for slots in (1, 4):
         out = {}
         for skip in (False, True):
-            ts = mcts.TreeSearch(G, sims, inf, slots=slots, seed=9, skip_unread_rows=skip)
+            ts = mcts.TreeSearch(G, sims, inf, slots=slots, seed=9, skip_unread_rows=skip, share_equal_leaves=False)
             assert ts.skip_unread_rows == skip
             action, policy, sum_n = ts.search(rb, rh, active=active, selfplay=True)
             hist = ts.leaf_histogram().sum(0).cpu().numpy()
@@ -508,3 +508,40 @@ def test_packed_records_equal_the_row_wise_records():
             assert all(np.array_equal(np.asarray(u), np.asarray(v)) for u, v in zip(x, y)), gid
         rows += len(a[1])
     print(f"{total} games, {rows} rows: packed batches == row-wise records")
+
+
+@pytest.mark.gpu
+def test_sharing_equal_leaves_does_not_change_the_search():
+    """TreeSearch(share_equal_leaves=True) (default with InferenceNet): equal leaves of a batch -- 256 trees searching the
+    SAME opening position and positions a few plies in, one and four leaves in flight -- are evaluated once
+    (hive_leaf_dedup_launch) and the duplicates take the representative's tower output before the heads.  Actions, visit
+    policies and totals must be identical to the search that evaluates every needed row, with far fewer rows evaluated."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd import batch, mcts
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    torch.manual_seed(0)
+    inf = InferenceNet(ChessNet().cuda().eval(), dtype=torch.bfloat16)
+    G, sims = 256, 30
+    B = batch.BoardBatch(G)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for plies in (0, 2):
+        for _ in range(plies):                                   # a couple of random moves: partly equal positions
+            _, count, lst = B.legal(want_list=True)
+            from hive_alphazero_amd.playout import pick_uniform
+            a = pick_uniform(count, lst, gen)
+            a = torch.where(torch.arange(G, device="cuda") % 4 == 0, a, a[0].expand(G).clone())   # 3 of 4 games follow game 0
+            B.step(a, sync=False)
+        rb, rh = B.export_state()
+        for slots in (1, 4):
+            out = {}
+            for share in (False, True):
+                ts = mcts.TreeSearch(G, sims, inf, slots=slots, seed=5, share_equal_leaves=share)
+                assert ts.share_equal_leaves == share
+                action, policy, sum_n = ts.search(rb, rh, selfplay=True)
+                out[share] = (action.clone(), policy.clone(), sum_n.clone(), int(ts.evals_run.item()))
+                ts.close()
+            assert all(torch.equal(x, y) for x, y in zip(out[False][:3], out[True][:3])), (plies, slots)
+            print(f"plies {plies} slots {slots}: rows evaluated {out[False][3]} -> {out[True][3]}")
+            assert out[True][3] < 0.7 * out[False][3]
+    assert B.illegal_count() == 0
+    B.close()

@@ -767,3 +767,36 @@ def test_inference_net_row_selection_keeps_the_selected_rows_bit_identical(dtype
     t_on, t_off = ms(on), ms(off)
     print(f"1024-row forward: every row {t_on:.3f} ms, no row {t_off:.3f} ms")
     assert t_off < 0.25 * t_on
+
+
+@pytest.mark.gpu
+def test_inference_net_equal_rows_take_their_representatives_tower_output():
+    """InferenceNet(planes, need, rep): a duplicate row (switched off in `need`) gets the tower output of its
+    representative copied in before the heads (hive_nn_copy_rows), so EVERY row's p / v -- also a duplicate's -- carry the
+    bits of the plain forward: the head GEMMs still see each row at its own position (their results depend on the row
+    position at the last ulp: tools/row_position.py)."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    torch.manual_seed(4)
+    net = ChessNet().cuda().eval()
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    for B, use_graph in ((96, False), (1024, True)):
+        base = (torch.rand((B // 8, 12, 12, 56), device="cuda", generator=gen) < 0.08).to(torch.bfloat16)
+        which = torch.randint(0, B // 8, (B,), device="cuda", generator=gen)
+        x = base[which]
+        w = which.cpu().numpy()
+        first = {}
+        rep = np.arange(B, dtype=np.int32)
+        for i in range(B):
+            rep[i] = first.setdefault(int(w[i]), i)
+        need = torch.from_numpy((rep == np.arange(B)).astype(np.int8)).cuda()
+        trep = torch.from_numpy(rep).cuda()
+        plain = InferenceNet(net, dtype=torch.bfloat16, use_graph=use_graph)
+        p0, v0 = plain(x)
+        inf = InferenceNet(net, dtype=torch.bfloat16, use_graph=use_graph)
+        for _ in range(2):
+            p, v = inf(x, need=need, rep=trep)
+            assert torch.equal(p, p0) and torch.equal(v, v0), (B, use_graph)
+        assert int(need.sum()) <= B // 8
+        p, v = inf(x)                                          # back to the plain call on the same graph
+        assert torch.equal(p, p0) and torch.equal(v, v0)
