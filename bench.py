@@ -166,28 +166,40 @@ def selfplay_measure(args, rank, local_rank, world):
         sp.play_ply()                                       # graph capture / GEMM tuning outside the timed region
         torch.cuda.synchronize()
         sp.close()
-        sp = mcts.SelfPlay(args.games, args.sims, net, device=local_rank, slots=args.slots, seed=1234, keep_records=False,
-                           game_ids=range(lo, lo + args.games))
-        torch.cuda.synchronize()
-        ev0 = int(sp.search.evals_run.item())
-        t0 = time.perf_counter()
-        plies = 0
-        while True:
-            sp.play_ply()
-            plies += 1
-            if sp.running() == 0 or plies > 60:
-                break
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        launched = plies * args.games * args.sims           # every simulation hands over one board per game slot
-        executed = int(sp.search.evals_run.item()) - ev0 if sp.search.skip_unread_rows else launched
-        whole = {"games": sp.finished, "wall_s": round(el, 3), "plies_played": plies,
-                 "games_per_min": round(sp.finished / el * 60.0, 2),
-                 "mean_plies_per_game": round(sp.mean_game_length(), 2), "ms_per_ply": round(el / plies * 1e3, 2),
-                 "illegal_moves": sp.env.illegal_count(),
-                 "results": {"white": sp.white_wins, "black": sp.black_wins, "draw_or_cap": sp.draws}}
-        whole.update(_leaf_accounting(sp.leaf_histogram(), launched, executed, el))
-        sp.close()
+        def whole_games_leg(search_options):
+            sp = mcts.SelfPlay(args.games, args.sims, net, device=local_rank, slots=args.slots, seed=1234, keep_records=False,
+                               game_ids=range(lo, lo + args.games), search_options=search_options)
+            torch.cuda.synchronize()
+            ev0 = int(sp.search.evals_run.item())
+            t0 = time.perf_counter()
+            plies = 0
+            while True:
+                sp.play_ply()
+                plies += 1
+                if sp.running() == 0 or plies > 60:
+                    break
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            launched = plies * args.games * args.sims           # every simulation hands over one board per game slot
+            executed = int(sp.search.evals_run.item()) - ev0 if sp.search.skip_unread_rows else launched
+            leg = {"games": sp.finished, "wall_s": round(el, 3), "plies_played": plies,
+                   "games_per_min": round(sp.finished / el * 60.0, 2),
+                   "mean_plies_per_game": round(sp.mean_game_length(), 2), "ms_per_ply": round(el / plies * 1e3, 2),
+                   "illegal_moves": sp.env.illegal_count(),
+                   "results": {"white": sp.white_wins, "black": sp.black_wins, "draw_or_cap": sp.draws},
+                   "leaf_batch": {"skip_unread_rows": sp.search.skip_unread_rows, "share_equal_leaves": sp.search.share_equal_leaves}}
+            leg.update(_leaf_accounting(sp.leaf_histogram(), launched, executed, el))
+            sp.close()
+            return leg
+
+        whole = whole_games_leg(None)
+        if args.every_row:
+            # the same games with every launched row evaluated (no row skipped, no equal leaves shared): the search and the
+            # games are identical bit for bit (tests/test_gpu_search.py), only the rows the tower computes differ
+            every = whole_games_leg({"skip_unread_rows": False})
+            out["whole_games_every_row_evaluated"] = {k: every[k] for k in ("games", "wall_s", "games_per_min", "ms_per_ply", "results",
+                                                                           "leaf_batch", "leaf_rows_launched", "leaf_evals_executed",
+                                                                           "roofline")}
         out["whole_games"] = whole
         out["games_per_min"] = whole["games_per_min"]
 
@@ -490,6 +502,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
                     "the multi-rank path on a single GPU")
     ap.add_argument("--net-dtype", default="bf16", choices=["bf16", "fp16"], help="leaf-evaluator precision of the self-play legs")
+    ap.add_argument("--no-every-row", dest="every_row", action="store_false",
+                    help="skip the whole-games leg that evaluates every launched row (no row skipping, no shared leaves)")
     ap.add_argument("--no-records", dest="records", action="store_false", help="skip the records-on whole-game self-play leg")
     ap.add_argument("--no-worker", dest="worker", action="store_false", help="skip the SelfPlayWorker (spawned producer) leg")
     ap.add_argument("--encode-boards", type=int, default=65536, help="boards per launch of the planes-writer side measurement (0 = skip)")
