@@ -534,6 +534,62 @@ def test_compact_games_widen_to_trainer_tensors_on_the_gpu():
     assert empty[0].shape == (0, 56, 12, 12) and empty[1].shape == (0, 1584) and empty[2].shape == (0,)
 
 
+def _replay_game_through_the_oracle(value_white, plies, gid):
+    """One recorded game (value_white, plies, game id) judged by the CPU oracle: -> (plies checked, passes).  See
+    test_finished_selfplay_games_replay_through_the_oracle for what is asserted."""
+    from oracle import oracle_py as O
+    from hive_alphazero_amd import records
+    plies_checked = passes = 0
+    g = O.OracleGame()
+    planes = [records.unpack_features(w, t, records.history_planes(hw, hl)) for (w, hw, hl, t, pol, mover) in plies]
+    for k, (w, hw, hl, t, pol, mover) in enumerate(plies):
+        assert g.turn == t and mover == (0 if t % 2 == 1 else 1), (gid, k)
+        assert np.array_equal(planes[k], g.encode_board().astype(np.float64)), (gid, k)      # recorded == oracle planes
+        legal = g.actions()
+        support = np.flatnonzero(pol).tolist()
+        assert set(support) <= set(legal), (gid, k)
+        plies_checked += 1
+        if not legal:
+            assert pol.sum() == 0
+            g.move(-1)
+            passes += 1
+            continue
+        # (when max W < 0 the policy is the masked prior renormalised the reference's way, p / (sum p + 1e-8),
+        # solo_play.py:304-313,372-373: with one legal move of prior 9e-5 that is 0.99989 -- seen in a 1024-game soak)
+        assert abs(pol.sum() - 1.0) < 2e-3, (gid, k, t, float(pol.sum()), len(legal), np.flatnonzero(pol).size)
+        found = None
+        if k + 1 < len(plies):
+            for a in legal:                    # (not only the policy's support: turns 1..6 resample with uniform noise)
+                nxt = g.copy()
+                nxt.move(a)
+                if nxt.turn == plies[k + 1][3] and np.array_equal(nxt.encode_board().astype(np.float64), planes[k + 1]):
+                    found = a
+                    break
+        else:                                  # the last ply: some legal move ends the game the way it was scored
+            for a in legal:
+                nxt = g.copy()
+                nxt.move(a)
+                over, w_ = nxt.game_is_over()
+                vw = 1 if w_ == 1 else (-1 if w_ == 2 else 0)
+                if (over and vw == value_white) or (not over and nxt.turn >= 55 and value_white == 0):
+                    found = a
+                    break
+        assert found is not None, (gid, k, t)
+        g.move(found)
+    over, w_ = g.game_is_over()
+    assert over or g.turn >= 55, gid
+    assert value_white == (1 if w_ == 1 else (-1 if w_ == 2 else 0)) or (not over and value_white == 0), gid
+    rows = records.rows_from_game((value_white, plies, gid))
+    n_side = [sum(1 for p in plies if p[5] == s) for s in (0, 1)]
+    seen = [0, 0]
+    for (state, policy, value, lens), p in zip(rows, plies):
+        side = p[5]
+        seen[side] += 1
+        assert lens == [n_side[side], seen[side]]
+        assert value == (-1 if value_white == 0 else (value_white if side == 0 else -value_white))
+    return plies_checked, passes
+
+
 def test_finished_selfplay_games_replay_through_the_oracle(bf16_net):
     """The whole producer chain -- noisy search, move resampling on turns 1..6, env step, per-ply records, scoring -- for
     128 games played to their end (8 simulations per move, bf16 network), judged by the CPU oracle instead of by the GPU's
@@ -562,57 +618,42 @@ def test_finished_selfplay_games_replay_through_the_oracle(bf16_net):
     assert sorted(e[2] for e in games) == list(range(G))
     decisive = plies_checked = passes = 0
     for value_white, plies, gid in games:
-        g = O.OracleGame()
-        planes = [records.unpack_features(w, t, records.history_planes(hw, hl)) for (w, hw, hl, t, pol, mover) in plies]
-        for k, (w, hw, hl, t, pol, mover) in enumerate(plies):
-            assert g.turn == t and mover == (0 if t % 2 == 1 else 1), (gid, k)
-            assert np.array_equal(planes[k], g.encode_board().astype(np.float64)), (gid, k)      # recorded == oracle planes
-            legal = g.actions()
-            support = np.flatnonzero(pol).tolist()
-            assert set(support) <= set(legal), (gid, k)
-            plies_checked += 1
-            if not legal:
-                assert pol.sum() == 0
-                g.move(-1)
-                passes += 1
-                continue
-            # (when max W < 0 the policy is the masked prior renormalised the reference's way, p / (sum p + 1e-8),
-            # solo_play.py:304-313,372-373: with one legal move of prior 9e-5 that is 0.99989 -- seen in a 1024-game soak)
-            assert abs(pol.sum() - 1.0) < 2e-3, (gid, k, t, float(pol.sum()), len(legal), np.flatnonzero(pol).size)
-            found = None
-            if k + 1 < len(plies):
-                for a in legal:                    # (not only the policy's support: turns 1..6 resample with uniform noise)
-                    nxt = g.copy()
-                    nxt.move(a)
-                    if nxt.turn == plies[k + 1][3] and np.array_equal(nxt.encode_board().astype(np.float64), planes[k + 1]):
-                        found = a
-                        break
-            else:                                  # the last ply: some legal move ends the game the way it was scored
-                for a in legal:
-                    nxt = g.copy()
-                    nxt.move(a)
-                    over, w_ = nxt.game_is_over()
-                    vw = 1 if w_ == 1 else (-1 if w_ == 2 else 0)
-                    if (over and vw == value_white) or (not over and nxt.turn >= 55 and value_white == 0):
-                        found = a
-                        break
-            assert found is not None, (gid, k, t)
-            g.move(found)
-        over, w_ = g.game_is_over()
-        assert over or g.turn >= 55, gid
-        assert value_white == (1 if w_ == 1 else (-1 if w_ == 2 else 0)) or (not over and value_white == 0), gid
-        decisive += int(value_white != 0)
-        rows = records.rows_from_game((value_white, plies, gid))
-        n_side = [sum(1 for p in plies if p[5] == s) for s in (0, 1)]
-        seen = [0, 0]
-        for (state, policy, value, lens), p in zip(rows, plies):
-            side = p[5]
-            seen[side] += 1
-            assert lens == [n_side[side], seen[side]]
-            assert value == (-1 if value_white == 0 else (value_white if side == 0 else -value_white))
+        c, p_ = _replay_game_through_the_oracle(value_white, plies, gid)
+        plies_checked, passes, decisive = plies_checked + c, passes + p_, decisive + int(value_white != 0)
     print(f"oracle replay: {G} games, {plies_checked} plies, {passes} passes, {decisive} decisive games")
     assert plies_checked > 40 * G
     sp.close()
+
+
+def test_selfplay_worker_files_replay_through_the_oracle(tmp_path):
+    """The PRODUCER end to end, judged by the oracle: SelfPlayWorker (spawned child, compact format) plays three rounds of
+    games per slot -- finished slots are refilled from the id shard, games end on different plies -- with the default
+    engine (two tower chains, unread rows skipped, equal leaves shared, packed record batches through the queue, files
+    written on writer threads); every game is then READ BACK FROM THE FILES and replayed through oracle_py.OracleGame
+    exactly as test_finished_selfplay_games_replay_through_the_oracle does, and the lazy `results` mapping must hold the
+    same games.  HIVE_SOAK_WORKER_GAMES / HIVE_SOAK_SIMS scale it up (3072 x 50: ~1 min of play + the replay)."""
+    from hive_alphazero_amd import records
+    from hive_alphazero_amd.self_play import SelfPlayWorker
+    total, sims = int(os.environ.get("HIVE_SOAK_WORKER_GAMES", "48")), int(os.environ.get("HIVE_SOAK_SIMS", "6"))
+    per_gpu = max(16, total // 3)
+    w = SelfPlayWorker(total_games=total, games_per_gpu=per_gpu, sims=sims, gpus=[0], seed=11, datapath=str(tmp_path),
+                       games_per_file=max(7, total // 5), report_every=0, row_format="compact", log=lambda *_: None)
+    res = w.start(timeout_s=900)
+    assert list(res) == list(range(total)) and w.leaf_kinds.get("root_evaluated", 0) > 0
+    loaded = [g for f in w.files for g in records.load_games(f)]
+    assert sorted(g[2] for g in loaded) == list(range(total))
+    plies_checked = passes = decisive = 0
+    lengths = set()
+    for value_white, plies, gid in loaded:
+        c, p_ = _replay_game_through_the_oracle(value_white, plies, gid)
+        plies_checked, passes, decisive = plies_checked + c, passes + p_, decisive + int(value_white != 0)
+        lengths.add(len(plies))
+        mine = res[gid]
+        assert mine[0] == value_white and len(mine[1]) == len(plies)
+        assert all(np.array_equal(np.asarray(u), np.asarray(v)) for x, y in zip(mine[1], plies) for u, v in zip(x, y))
+    print(f"worker files -> oracle: {total} games in {len(w.files)} files, {plies_checked} plies, {passes} passes, "
+          f"{decisive} decisive games, {len(lengths)} distinct game lengths")
+    assert plies_checked > 40 * total
 
 
 def test_config3_shards_of_8192_game_ids_rehearsed_on_one_gpu(bf16_net):
