@@ -402,70 +402,68 @@ __device__ __forceinline__ void pin_phase(Smem<FULL> &sm, int wave, int lane)
 __device__ __forceinline__ bool bb_test(BB x, unsigned cell) { return bb_any(bb_and(x, bb_bit(cell))); }
 
 // GamePlay.encode_action (env_hive.py:287-304): {slot: destination board} -> ascending action ids.  Action id =
-// cell * 11 + slot, i.e. the bit index of the 11 x 144 slot-major bit matrix TRANSPOSED into a 1584-bit id-ordered mask
-// (50 words in LDS).  Two steps:
-//   scatter   the set bits of destination words are ORed into the id-ordered mask (ds_or_b32).  In the fused movegen launch
-//             every (board, slot) quad does this for its own two words as soon as it has them -- spread over all eleven
-//             waves and, for ten of them, off the critical path; `transpose_dest_board` is the one-wave form for callers
-//             that only hold the 66-word destination image.
-//   emit      lane j owns word j of the mask: six ballots + v_mbcnt over the words' popcounts give every word its place in
-//             the list, its set bits are laid down in an LDS row, and the row leaves as one coalesced 8-byte store per
-//             lane (-1 padded).
-__device__ __forceinline__ void scatter_slot_bits(uint32_t *idmask, unsigned long long w, unsigned row0, unsigned slot)
-{
-    // w: four board rows of one slot's destination board (row r at bits 16 r .. 16 r + 11); row0 = the first of them
-    while (w) {
-        const unsigned bidx = (unsigned)__builtin_ctzll(w);
-        w &= w - 1ull;
-        const unsigned id = ((row0 + (bidx >> 4)) * 12u + (bidx & 15u)) * 11u + slot;
-        atomicOr(&idmask[id >> 5], 1u << (id & 31u));
-    }
-}
-
-__device__ __forceinline__ void transpose_dest_board(const uint32_t *dest, uint32_t *idmask, int lane)
-{
-    if (lane < 52) idmask[lane] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // same-wave LDS traffic only: program order suffices
-    __builtin_amdgcn_wave_barrier();
-    // lane l < 33: slot l / 3, word pair (l % 3) of that slot's six words = four board rows
-    if (lane < 33) {
-        const unsigned slot = (unsigned)lane / 3u, pair = (unsigned)lane - slot * 3u;
-        const unsigned long long w = (unsigned long long)dest[slot * 6u + 2u * pair] |
-                                     ((unsigned long long)dest[slot * 6u + 2u * pair + 1u] << 32);
-        scatter_slot_bits(idmask, w, 4u * pair, slot);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ void emit_id_list(const uint32_t *idmask, int16_t *rowbuf, int16_t *out, int lane)
+// cell * 11 + slot: the list is the 11 x 144 slot-major bit matrix read CELL-major.  A wave builds one board's list from
+// the board's destination image in LDS ([slot][6 words], the layout of the legal mask) and the OR of its eleven slot boards:
+//   1. the cells that are anybody's destination (~35 of 144) are compacted, in ascending order, into an LDS byte list
+//      (three passes of 64 cells: one bit test, one ballot, one v_mbcnt each);
+//   2. lane k takes the k-th such cell and gathers its bit from the eleven slot boards (eleven independent ds_reads at
+//      immediate offsets -- no per-bit atomics, no dependent LDS round trips); four ballots + v_mbcnt over the cells'
+//      popcounts give every cell its place in the list, its <= 11 ids are laid down in an LDS row;
+//   3. the row leaves as one coalesced 8-byte store per lane (-1 padded).
+// Cells ascend with the lanes, slots ascend inside a cell: the list is sorted.
+__device__ __forceinline__ void emit_id_list(const uint32_t *img, const uint32_t *any, uint8_t *cells, int16_t *rowbuf,
+                                             int16_t *out, int lane)
 {
     reinterpret_cast<unsigned long long *>(rowbuf)[lane] = 0xFFFFFFFFFFFFFFFFull;      // four -1 entries per lane
-    uint32_t w = lane < 50 ? idmask[lane] : 0u;
-    const unsigned c = (unsigned)__popc(w);                     // <= 32: six bits
-    int pos = 0;
-    HIVE_UNROLL for (unsigned k = 0; k < 6u; ++k) {
-        const unsigned long long bal = __ballot((c >> k) & 1u);
-        pos += (int)(__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)) << k);
+    int ncell = 0;
+    HIVE_UNROLL for (int pass = 0; pass < 3; ++pass) {
+        const unsigned c = (unsigned)(pass * 64 + lane);
+        const unsigned cc = c < (unsigned)kCells ? c : 0u;
+        const unsigned row = cc / 12u, col = cc - row * 12u;
+        const bool has = c < (unsigned)kCells && ((any[row >> 1] >> (((row & 1u) << 4) | col)) & 1u);
+        const unsigned long long bal = __ballot(has);
+        if (has)
+            cells[ncell + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (uint8_t)c;
+        ncell += (int)__popcll(bal);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (the -1 fill precedes the ids in program order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (same-wave LDS traffic only: program order suffices)
     __builtin_amdgcn_wave_barrier();
-    while (w) {                                                 // this word's ids in ascending order
-        const unsigned bidx = (unsigned)__builtin_ctz(w);
-        w &= w - 1u;
-        if (pos < HIVE_LIST_CAP) rowbuf[pos] = (int16_t)((unsigned)lane * 32u + bidx);
-        ++pos;
+    int base = 0;
+    for (int k0 = 0; k0 < ncell; k0 += 64) {                    // one trip unless more than 64 cells are destinations
+        const bool act = k0 + lane < ncell;
+        const unsigned c = act ? (unsigned)cells[k0 + lane] : 0u;
+        const unsigned row = c / 12u, col = c - row * 12u;
+        const uint32_t *w = img + (row >> 1);
+        const unsigned sh = ((row & 1u) << 4) | col;
+        unsigned v = 0u;
+        HIVE_UNROLL for (unsigned s = 0; s < 11u; ++s) v |= ((w[s * 6u] >> sh) & 1u) << s;
+        if (!act) v = 0u;
+        const unsigned cnt = (unsigned)__popc(v);                // <= 11: four bits
+        int pos = base;
+        HIVE_UNROLL for (unsigned k = 0; k < 4u; ++k) {
+            const unsigned long long bal = __ballot((cnt >> k) & 1u);
+            pos += (int)(__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)) << k);
+            base += (int)(__popcll(bal) << k);
+        }
+        while (v) {                                             // this cell's ids in ascending slot order
+            const unsigned sl = (unsigned)__builtin_ctz(v);
+            v &= v - 1u;
+            if (pos < HIVE_LIST_CAP) rowbuf[pos] = (int16_t)(c * 11u + sl);
+            ++pos;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     reinterpret_cast<unsigned long long *>(out)[lane] = reinterpret_cast<const unsigned long long *>(rowbuf)[lane];
-    __builtin_amdgcn_wave_barrier();                            // (the row buffer may be reused by this wave)
+    __builtin_amdgcn_wave_barrier();                            // (the row and cell buffers may be reused by this wave)
 }
 
-// LDS of the fused list variant: the id-ordered masks of the workgroup's 16 boards and one list row per wave
+// LDS of the fused list variant: the destination images of the workgroup's 16 boards and one list row per wave
 template <bool LIST> struct ListMem { uint32_t pad; };
 template <> struct alignas(16) ListMem<true> {
-    uint32_t idmask[16][52];
+    uint32_t dest[16][11][6];
+    uint32_t any[16][6];                   // OR of a board's eleven destination boards
+    uint8_t cells[NW][kCells];             // per list-building wave: the cells that are somebody's destination
     alignas(8) int16_t rowbuf[NW][HIVE_LIST_CAP];
 };
 
@@ -529,7 +527,7 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     for (int i = tid; i < G * kCells / 4; i += nthreads)
         reinterpret_cast<uint4 *>(&sm.cellmask[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
     if constexpr (LIST)
-        for (int i = tid; i < 16 * 52; i += nthreads) (&lm.idmask[0][0])[i] = 0u;
+        if (tid < 16 * 6) (&lm.any[0][0])[tid] = 0u;
     if (tid == 0) { sm.done = 0; sm.pin_done = 0; sm.adj_done = 0; }
     if (tid < G) { sm.nlegal[tid] = 0; sm.pinmask[tid] = 0u; }
     if (tid < G * 4) reinterpret_cast<uint4 *>(sm.state[tid >> 2])[tid & 3] = rec_part;
@@ -592,9 +590,12 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         if (valid && mask != nullptr && (lane & 3) < 3)
             *reinterpret_cast<uint2 *>(mask + (gbase + bl) * HIVE_MASK_WORDS + wv * 6 + 2 * (lane & 3)) =
                 make_uint2(pc.D.lo, pc.D.hi);
-        if constexpr (LIST)       // this quad's slot bits into its board's id-ordered mask (lane 3 of a quad holds zero)
-            scatter_slot_bits(lm.idmask[bl], (unsigned long long)pc.D.lo | ((unsigned long long)pc.D.hi << 32),
-                              4u * (unsigned)(lane & 3), (unsigned)wv);
+        if constexpr (LIST)       // ... and stays in LDS for the list builders (every (board, slot) quad writes: no clearing)
+            if ((lane & 3) < 3) {
+                *reinterpret_cast<uint2 *>(&lm.dest[bl][wv][2 * (lane & 3)]) = make_uint2(pc.D.lo, pc.D.hi);
+                if (pc.D.lo) atomicOr(&lm.any[bl][2 * (lane & 3)], pc.D.lo);
+                if (pc.D.hi) atomicOr(&lm.any[bl][2 * (lane & 3) + 1], pc.D.hi);
+            }
         const int nd = __popc(pc.D.lo) + __popc(pc.D.hi);       // destination sets of different pieces are disjoint
         if (nd) atomicAdd(&sm.nlegal[bl], nd);
     }
@@ -654,8 +655,18 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         HIVE_STAMP(6);
         const int nbl = (int)((n - gbase) < G ? (n - gbase) : G);
         if (wave_id == 0 && count != nullptr && lane < nbl) count[gbase + lane] = sm.nlegal[lane];
-        for (int b = wave_id; b < nbl; b += NW)
-            emit_id_list(lm.idmask[b], lm.rowbuf[wave_id], list + (gbase + b) * HIVE_LIST_CAP, lane);
+        // 16 boards on 11 waves, four per SIMD (waves land on SIMD wave_id mod 4: SIMD 3 holds two waves, the others three):
+        // every wave builds board wave_id, waves 3 and 7 (SIMD 3) and one wave of each other SIMD (4, 5, 6) a second one
+        static_assert(G == 16 || !LIST, "the list builders are shared out for 16 boards on 11 waves");
+        // (two boards in lock step inside one wave, and 16 boards as 16 equal shares, were built and measured: 9.24 us
+        // against 9.27 -- the eleven waves together are short of VALU issue slots here, not of latency hiding)
+        if (wave_id < nbl)
+            emit_id_list(&lm.dest[wave_id][0][0], lm.any[wave_id], lm.cells[wave_id], lm.rowbuf[wave_id],
+                         list + (gbase + wave_id) * HIVE_LIST_CAP, lane);
+        const int second = wave_id == 3 ? 11 : wave_id == 7 ? 12 : (wave_id >= 4 && wave_id <= 6) ? 9 + wave_id : -1;
+        if (second >= 0 && second < nbl)
+            emit_id_list(&lm.dest[second][0][0], lm.any[second], lm.cells[wave_id], lm.rowbuf[wave_id],
+                         list + (gbase + second) * HIVE_LIST_CAP, lane);
         HIVE_STAMP(7);
         return;
     }
@@ -676,12 +687,13 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     }
 }
 
-// GamePlay.encode_action over an existing mask (one wave per board; build_id_list above).
+// GamePlay.encode_action over an existing mask (one wave per board; emit_id_list above).
 __global__ void __launch_bounds__(256)
 hive_list_kernel(const uint32_t *__restrict__ mask, int n, int16_t *__restrict__ list)
 {
     __shared__ uint32_t dest[4][HIVE_MASK_WORDS + 2];
-    __shared__ uint32_t idmask[4][52];
+    __shared__ uint32_t any[4][6];
+    __shared__ uint8_t cells[4][kCells];
     __shared__ __attribute__((aligned(8))) int16_t rowbuf[4][HIVE_LIST_CAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long b = (long long)blockIdx.x * 4 + wv;
@@ -689,8 +701,16 @@ hive_list_kernel(const uint32_t *__restrict__ mask, int n, int16_t *__restrict__
     const uint32_t *m = mask + b * HIVE_MASK_WORDS;
     dest[wv][lane] = m[lane];
     if (lane < HIVE_MASK_WORDS - 64) dest[wv][64 + lane] = m[64 + lane];
-    transpose_dest_board(dest[wv], idmask[wv], lane);
-    emit_id_list(idmask[wv], rowbuf[wv], list + b * HIVE_LIST_CAP, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // same-wave LDS traffic only: program order suffices
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 6) {
+        uint32_t o = 0u;
+        HIVE_UNROLL for (int sl = 0; sl < 11; ++sl) o |= dest[wv][sl * 6 + lane];
+        any[wv][lane] = o;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    emit_id_list(dest[wv], any[wv], cells[wv], rowbuf[wv], list + b * HIVE_LIST_CAP, lane);
 }
 
 // value encoders for the plane writer
