@@ -411,6 +411,19 @@ __device__ __forceinline__ bool bb_test(BB x, unsigned cell) { return bb_any(bb_
 //      popcounts give every cell its place in the list, its <= 11 ids are laid down in an LDS row;
 //   3. the row leaves as one coalesced 8-byte store per lane (-1 padded).
 // Cells ascend with the lanes, slots ascend inside a cell: the list is sorted.
+// inclusive prefix sum over the 64 lanes of a wave: Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8, zero fill),
+// then lane 15 of row 0 / 2 into row 1 / 3 (row_bcast:15) and lane 31 into rows 2 and 3 (row_bcast:31)
+__device__ __forceinline__ int wave_inclusive_sum(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+    return x;
+}
+
 __device__ __forceinline__ void emit_id_list(const uint32_t *img, const uint32_t *any, uint8_t *cells, int16_t *rowbuf,
                                              int16_t *out, int lane)
 {
@@ -438,13 +451,10 @@ __device__ __forceinline__ void emit_id_list(const uint32_t *img, const uint32_t
         unsigned v = 0u;
         HIVE_UNROLL for (unsigned s = 0; s < 11u; ++s) v |= ((w[s * 6u] >> sh) & 1u) << s;
         if (!act) v = 0u;
-        const unsigned cnt = (unsigned)__popc(v);                // <= 11: four bits
-        int pos = base;
-        HIVE_UNROLL for (unsigned k = 0; k < 4u; ++k) {
-            const unsigned long long bal = __ballot((cnt >> k) & 1u);
-            pos += (int)(__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)) << k);
-            base += (int)(__popcll(bal) << k);
-        }
+        const int cnt = __popc(v);                              // <= 11 ids per cell
+        const int upto = wave_inclusive_sum(cnt);               // six DPP adds (four ballots + v_mbcnt took twenty instructions)
+        int pos = base + upto - cnt;
+        base += __builtin_amdgcn_readlane(upto, 63);
         while (v) {                                             // this cell's ids in ascending slot order
             const unsigned sl = (unsigned)__builtin_ctz(v);
             v &= v - 1u;
