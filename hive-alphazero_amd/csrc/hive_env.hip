@@ -449,7 +449,7 @@ __device__ __forceinline__ void emit_id_list(const uint32_t *img, const uint32_t
         const uint32_t *w = img + (row >> 1);
         const unsigned sh = ((row & 1u) << 4) | col;
         unsigned v = 0u;
-        HIVE_UNROLL for (unsigned s = 0; s < 11u; ++s) v |= ((w[s * 6u] >> sh) & 1u) << s;
+        HIVE_UNROLL for (int s = 10; s >= 0; --s) v = (v << 1) | __builtin_amdgcn_ubfe(w[s * 6], sh, 1u);      // v_bfe_u32 + v_lshl_or_b32 per slot
         if (!act) v = 0u;
         const int cnt = __popc(v);                              // <= 11 ids per cell
         const int upto = wave_inclusive_sum(cnt);               // six DPP adds (four ballots + v_mbcnt took twenty instructions)
