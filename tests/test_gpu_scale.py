@@ -631,29 +631,36 @@ def test_selfplay_worker_files_replay_through_the_oracle(tmp_path):
     engine (two tower chains, unread rows skipped, equal leaves shared, packed record batches through the queue, files
     written on writer threads); every game is then READ BACK FROM THE FILES and replayed through oracle_py.OracleGame
     exactly as test_finished_selfplay_games_replay_through_the_oracle does, and the lazy `results` mapping must hold the
-    same games.  HIVE_SOAK_WORKER_GAMES / HIVE_SOAK_SIMS scale it up (3072 x 50: ~1 min of play + the replay)."""
+    same games.  HIVE_SOAK_WORKER_GAMES / HIVE_SOAK_SIMS scale it up (2048 x 50: ~1 min of play + the replay); HIVE_SOAK_REPLAY = how
+    many of the games to replay (every total/REPLAY-th id) when the run is long, HIVE_SOAK_PER_GPU the engine's batch."""
     from hive_alphazero_amd import records
     from hive_alphazero_amd.self_play import SelfPlayWorker
     total, sims = int(os.environ.get("HIVE_SOAK_WORKER_GAMES", "48")), int(os.environ.get("HIVE_SOAK_SIMS", "6"))
-    per_gpu = max(16, total // 3)
+    per_gpu = int(os.environ.get("HIVE_SOAK_PER_GPU", max(16, total // 3)))
     w = SelfPlayWorker(total_games=total, games_per_gpu=per_gpu, sims=sims, gpus=[0], seed=11, datapath=str(tmp_path),
                        games_per_file=max(7, total // 5), report_every=0, row_format="compact", log=lambda *_: None)
-    res = w.start(timeout_s=900)
+    res = w.start(timeout_s=1100)
     assert list(res) == list(range(total)) and w.leaf_kinds.get("root_evaluated", 0) > 0
-    loaded = [g for f in w.files for g in records.load_games(f)]
-    assert sorted(g[2] for g in loaded) == list(range(total))
-    plies_checked = passes = decisive = 0
+    batches = [records.load_packed(f) for f in w.files]
+    assert sorted(int(i) for b_ in batches for i in b_["game_id"]) == list(range(total))
+    assert sum(len(b_["meta"]) for b_ in batches) == sum(w.game_lens)
+    plies_checked = passes = decisive = replayed = 0
     lengths = set()
-    for value_white, plies, gid in loaded:
-        c, p_ = _replay_game_through_the_oracle(value_white, plies, gid)
-        plies_checked, passes, decisive = plies_checked + c, passes + p_, decisive + int(value_white != 0)
-        lengths.add(len(plies))
-        mine = res[gid]
-        assert mine[0] == value_white and len(mine[1]) == len(plies)
-        assert all(np.array_equal(np.asarray(u), np.asarray(v)) for x, y in zip(mine[1], plies) for u, v in zip(x, y))
-    print(f"worker files -> oracle: {total} games in {len(w.files)} files, {plies_checked} plies, {passes} passes, "
-          f"{decisive} decisive games, {len(lengths)} distinct game lengths")
-    assert plies_checked > 40 * total
+    stride = max(1, total // int(os.environ.get("HIVE_SOAK_REPLAY", total)))      # long soaks replay every stride-th game
+    for b_ in batches:
+        lengths.update(np.diff(b_["game_ptr"]).tolist())
+        for g, gid in enumerate(b_["game_id"].tolist()):
+            if gid % stride:
+                continue
+            value_white, plies, _ = records.unpack_game(b_, g)
+            c, p_ = _replay_game_through_the_oracle(value_white, plies, gid)
+            plies_checked, passes, decisive, replayed = plies_checked + c, passes + p_, decisive + int(value_white != 0), replayed + 1
+            mine = res[gid]
+            assert mine[0] == value_white and len(mine[1]) == len(plies)
+            assert all(np.array_equal(np.asarray(u), np.asarray(v)) for x, y in zip(mine[1], plies) for u, v in zip(x, y))
+    print(f"worker files -> oracle: {total} games in {len(w.files)} files ({sum(w.game_lens)} rows), {replayed} replayed: "
+          f"{plies_checked} plies, {passes} passes, {decisive} decisive games; {len(lengths)} distinct game lengths")
+    assert plies_checked > 40 * replayed and replayed >= total // stride
 
 
 def test_config3_shards_of_8192_game_ids_rehearsed_on_one_gpu(bf16_net):
