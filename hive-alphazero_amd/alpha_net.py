@@ -619,8 +619,13 @@ class InferenceNet:
         finally:
             tn.tuning_enable(False)
 
-    accepts_need = True          # __call__ takes the row selection of hive_search_leaf_need (mcts.TreeSearch asks for this)
-    accepts_rep = True           # ... and the representatives of equal rows (hive_leaf_dedup_launch)
+    @property
+    def accepts_need(self):
+        """__call__ honours the row selection of hive_search_leaf_need (mcts.TreeSearch asks): the HIP tower only -- the
+        library path evaluates every row, and says so, so that the search's rows-evaluated counter stays true."""
+        return self.conv == "hip"
+
+    accepts_rep = accepts_need   # ... and the representatives of equal rows (hive_leaf_dedup_launch)
 
     def __call__(self, planes_hwc, need=None, rep=None):
         """need: int8[B] on the device (1 = this row's p / v will be read) or None = every row.  Rows flagged 0 come back
