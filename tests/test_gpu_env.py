@@ -366,6 +366,23 @@ def test_abi_argument_errors(hv):
     pl = B.encode(torch.float32, "hwc")
     assert float(pl[..., 31].min()) == 1.0 and float(pl.sum()) == 2 * 144.0
     B.close()
+    # the leaf-batch entry points of round 3 refuse what they cannot do instead of faulting
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    y = torch.zeros((4, 144, 256), dtype=torch.bfloat16, device="cuda")
+    rep = torch.arange(4, dtype=torch.int32, device="cuda")
+    assert L.hive_nn_copy_rows(P(y), P(rep), 4, 144 * 256 * 2, None) == 0
+    assert L.hive_nn_copy_rows(P(y), P(rep), 4, 10, None) == -1                 # rows must be a multiple of 16 bytes
+    assert L.hive_nn_copy_rows(P(y), None, 4, 144 * 256 * 2, None) == -1
+    assert L.hive_nn_copy_rows(ctypes.c_void_p(y.data_ptr() + 2), P(rep), 3, 144 * 256 * 2, None) == -1   # misaligned rows
+    w = torch.zeros((9 * 8 * 16 * 64 * 8,), dtype=torch.bfloat16, device="cuda")
+    bias = torch.zeros((256,), dtype=torch.float32, device="cuda")
+    need = torch.zeros((4,), dtype=torch.int8, device="cuda")
+    assert L.hive_nn_resblock_sel(P(y), P(w), P(bias), P(w), P(bias), P(y), 4, 2, P(need), None) == -1      # y aliases x
+    y2 = torch.full_like(y, 3.0)
+    assert L.hive_nn_resblock_sel(P(y), P(w), P(bias), P(w), P(bias), P(y2), 4, 2, P(need), None) == 0
+    torch.cuda.synchronize()
+    assert float(y2.float().min()) == 3.0                                          # no board selected: nothing written
+    assert L.hive_nn_resblock_sel(P(y), P(w), P(bias), P(w), P(bias), P(y2), 4, 9, P(need), None) == -1     # unknown dtype
 
 
 def test_planes_writer_streaming_launch_equals_small_launches(hv):
