@@ -456,8 +456,19 @@ def encode_measure(L, n=65536, steps=20):
         out[key] = {"kernel": name, "ms_per_launch": round(ms, 4), "Mboards_per_s": round(n / ms / 1e3, 2)}
         if key == "planes_writer":
             alg = n * (ENCODE_BYTES_PER_BOARD + 1152 + 64)
+            traffic, traffic_source = None, None
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_encode_counters.json")))
+            if files:                           # HBM bytes per launch from the round's PMC passes, scaled to this launch's boards
+                with open(files[-1]) as f:
+                    c = json.load(f)
+                k = c["hive_expand_kernel<2,0,true>"]
+                traffic = int((c["fetch_size_correction"] * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0
+                              * n / c["boards_per_dispatch"])
+                traffic_source = os.path.relpath(files[-1], ROOT) + ": " + c["source"]
             out[key]["roofline"] = {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                                    "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                    "traffic_source": traffic_source,
                                     "algorithmic_bytes_per_launch": alg,
                                     "note": "16,128 B written + 1,216 B read per board (history empty in this corpus); PMC "
                                             "FETCH/WRITE_SIZE passes: profiles/r03_encode_pmc.md"}
