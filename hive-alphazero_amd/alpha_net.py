@@ -537,26 +537,31 @@ class InferenceNet:
                                         ctypes.c_void_p(tb.data_ptr()), ctypes.c_void_p(bufs[1].data_ptr()), B, 19, dt,
                                         self.tower, st))
             return bufs[1].permute(0, 3, 1, 2)
-        if self.fuse_blocks and self.split_streams and B >= 512 and B % 2 == 0:
+        if self.fuse_blocks and self.split_streams and B >= 512:
             # Boards are independent: only the 19 blocks of ONE board are ordered.  A single stream makes every block a
-            # chip-wide barrier (the launch boundary); two half-batch chains on two streams let one half's tail and ramp
-            # run under the other half's work: 246 instead of 260 us per block at 1024 boards, same bits
-            # (tools/two_stream_chain.py; four / eight chains are slower again: they de-phase the weight streams)
-            half = B // 2
+            # chip-wide barrier (the launch boundary) and keeps every CU's two workgroups in the same phase; independent
+            # chains on two streams run one chain's tails, staging and epilogues under the other's tap loops.  Measured
+            # (tools/two_stream_chain.py, same bits): 1024 boards as 2 x 512: 246 instead of 260 us per block; 4096 boards
+            # as chains of 512 dealt onto two streams: 955 instead of 1003 (two chains of 2048: 998); more than two chains
+            # in flight, or chains of fewer than 256 boards, are slower again (they de-phase the weight streams).
+            if B <= 1024:
+                bounds = [(0, B // 2), (B // 2, B)]
+            else:
+                bounds = [(lo, min(lo + 512, B)) for lo in range(0, B, 512)]
             main = torch.cuda.current_stream(self.device)
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(self.device)
             side = self._side_stream
             side.wait_stream(main)
-            for lo, stream in ((0, main), (half, side)):
-                stp = ctypes.c_void_p(stream.cuda_stream)
+            for k, (lo, hi) in enumerate(bounds):
+                stp = ctypes.c_void_p((main if k % 2 == 0 else side).cuda_stream)
                 cur = 0
                 for w1, b1, w2, b2 in self.h_blocks:
                     nxt = (cur + 1) % 3
                     check(self._L.hive_nn_resblock_sel(ctypes.c_void_p(bufs[cur][lo:].data_ptr()), ctypes.c_void_p(w1.data_ptr()),
                                                        ctypes.c_void_p(b1.data_ptr()), ctypes.c_void_p(w2.data_ptr()),
                                                        ctypes.c_void_p(b2.data_ptr()), ctypes.c_void_p(bufs[nxt][lo:].data_ptr()),
-                                                       half, dt, needp(lo), stp))
+                                                       hi - lo, dt, needp(lo), stp))
                     cur = nxt
             if not torch.cuda.is_current_stream_capturing():      # (a captured graph owns its memory pool)
                 for t in bufs:

@@ -707,6 +707,13 @@ def test_inference_net_tower_forms_give_the_same_bits(dtype):
     for _ in range(3):
         pb, vb = two(xl)
         assert torch.equal(pa, pb) and torch.equal(va, vb)
+    # more than 1024 rows: chains of 512 boards (the last one shorter) dealt onto the two streams; an odd row count too
+    for rows in (2304, 1025):
+        xb = (torch.rand((rows, 12, 12, 56), device="cuda") < 0.08).to(dtype)
+        pa, va = one(xb)
+        for _ in range(2):
+            pb, vb = two(xb)
+            assert torch.equal(pa, pb) and torch.equal(va, vb), rows
     engines = {t: InferenceNet(net, dtype=dtype, tower=t) for t in (1, 2, 3)}
     for t, inf in engines.items():
         p, v = inf(x)

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from hive_alphazero_amd import _lib
 L = _lib.load()
-B, NBLK = 1024, 19
+B, NBLK = (int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[1] in ("parts", "seq") else 1024), 19
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 torch.manual_seed(0)
 x = torch.randn((B, 144, 256), device="cuda").to(torch.bfloat16)
@@ -33,6 +33,16 @@ def two(parts=2):
         s.wait_event(ev)
         chain(k * (B // parts), B // parts, s)
         e = torch.cuda.Event(); e.record(s); main.wait_event(e)
+def seq(chunk, nstreams):
+    """chains of `chunk` boards, dealt round-robin onto `nstreams` streams (chains of one stream run one after another)"""
+    ev = torch.cuda.Event(); ev.record(main)
+    streams = pool[:nstreams]
+    for s_ in streams:
+        s_.wait_event(ev)
+    for k in range(B // chunk):
+        chain(k * chunk, chunk, streams[k % nstreams])
+    for s_ in streams:
+        e = torch.cuda.Event(); e.record(s_); main.wait_event(e)
 def two_upto(count):
     """what a compacted leaf batch would run: boards [0, 512) and [512, count) -- the second chain is shorter"""
     ev = torch.cuda.Event(); ev.record(main)
@@ -53,7 +63,12 @@ def two_even(count):
         e = torch.cuda.Event(); e.record(s); main.wait_event(e)
 ref = None
 forms = (("one stream x 1024", one), ("two streams x 512", two), ("four streams x 256", lambda: two(4)), ("eight streams x 128", lambda: two(8)))
-if len(sys.argv) > 1 and sys.argv[1] == "counts":
+if len(sys.argv) > 1 and sys.argv[1] == "seq":            # python tools/two_stream_chain.py seq 4096 512:2 1024:2 512:4
+    forms = (("one chain", one),) + tuple((f"chains of {c} on {k} streams", (lambda c=c, k=k: seq(c, k)))
+                                          for c, k in (map(int, a.split(":")) for a in sys.argv[3:]))
+elif len(sys.argv) > 1 and sys.argv[1] == "parts":          # python tools/two_stream_chain.py parts 4096 1 2 4 8
+    forms = tuple((f"{k} chain(s) x {B // k}", (one if k == 1 else (lambda k=k: two(k)))) for k in map(int, sys.argv[3:]))
+elif len(sys.argv) > 1 and sys.argv[1] == "counts":
     forms = (("two streams x 512", two),) + tuple((f"512 + {c - 512}", (lambda c=c: two_upto(c))) for c in (992, 960, 928, 896, 768)) \
         + tuple((f"2 x {c // 2}", (lambda c=c: two_even(c))) for c in (992, 960, 896, 768))
 times = {k: [] for k, _ in forms}
@@ -61,7 +76,7 @@ for name, fn in forms:
     fn(); torch.cuda.synchronize()
     out = (y1 if NBLK % 2 else y2).clone()
     ref = out if ref is None else ref
-    if "+" not in name and " x " in name and not name.startswith("2 x"):
+    if "+" not in name and (" x " in name or "chain" in name) and not name.startswith("2 x"):
         print(name, "same bits as the single chain:", bool(torch.equal(out, ref)))
 for _ in range(8):
     for name, fn in forms:
