@@ -39,8 +39,8 @@ def seq(chunk, nstreams):
     streams = pool[:nstreams]
     for s_ in streams:
         s_.wait_event(ev)
-    for k in range(B // chunk):
-        chain(k * chunk, chunk, streams[k % nstreams])
+    for k, lo in enumerate(range(0, B, chunk)):          # (the last chain takes the remainder)
+        chain(lo, min(chunk, B - lo), streams[k % nstreams])
     for s_ in streams:
         e = torch.cuda.Event(); e.record(s_); main.wait_event(e)
 def two_upto(count):
