@@ -6,7 +6,6 @@ torch.manual_seed(0)
 net = ChessNet().cuda().eval()
 one = InferenceNet(net, dtype=torch.bfloat16); one.split_streams = False
 two = InferenceNet(net, dtype=torch.bfloat16)
-two_force = InferenceNet(net, dtype=torch.bfloat16)
 for B in (256, 384, 512, 768, 1024, 2048, 4096):
     x = (torch.rand((B, 12, 12, 56), device="cuda") < 0.08).to(torch.bfloat16)
     t = {}
