@@ -508,6 +508,31 @@ def test_packed_records_equal_the_row_wise_records():
             assert all(np.array_equal(np.asarray(u), np.asarray(v)) for u, v in zip(x, y)), gid
         rows += len(a[1])
     print(f"{total} games, {rows} rows: packed batches == row-wise records")
+    # staggered start (the first game of most slots begins mid-game and is not recorded): same games kept, same rows
+    kept = {}
+    for packed in (False, True):
+        sp = mcts.SelfPlay(24, 4, inf, seed=5, game_ids=iter(range(60)), packed_records=packed, max_finished_kept=4096)
+        sp.stagger(seed=3)
+        got = []
+        for _ in range(200):
+            sp.play_ply()
+            if packed:
+                b = sp.drain_finished_packed()
+                if b is not None:
+                    got += [records.unpack_game(b, g) for g in range(records.packed_games(b))]
+            else:
+                got += sp.drain_finished()
+            if sp.running() == 0:
+                break
+        assert sp.running() == 0 and sp.dropped_games == 0
+        kept[packed] = ({g[2]: g for g in got}, sp.unrecorded_games)
+        sp.close()
+    assert kept[False][1] == kept[True][1] > 0 and sorted(kept[False][0]) == sorted(kept[True][0])
+    for gid, a in kept[False][0].items():
+        b = kept[True][0][gid]
+        assert a[0] == b[0] and len(a[1]) == len(b[1])
+        assert all(np.array_equal(np.asarray(u), np.asarray(v)) for x, y in zip(a[1], b[1]) for u, v in zip(x, y)), gid
+    print(f"staggered: {len(kept[True][0])} games recorded, {kept[True][1]} first games of a slot not recorded, in both forms")
 
 
 @pytest.mark.gpu
