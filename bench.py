@@ -496,6 +496,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--windows", type=int, default=25, help="timed regions of --steps launches each; value = their median")
     ap.add_argument("--boards", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sat-boards", type=int, default=1 << 20, help="batch size of the saturated side measurement")
@@ -572,22 +573,37 @@ def main():
     t_setup = time.perf_counter() - t_start
     for _ in range(args.warmup):
         step()
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record(stream)
-    for _ in range(args.steps):
-        step()
-    e1.record(stream)
-    barrier()
-    wall = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)
-    # the timed region is the K launches between the two barrier + synchronize brackets, measured with HIP events on the
-    # launch stream (a host clock around a 0.2 ms region mostly measures the closing synchronize); max over ranks
-    tt = torch.tensor([dev_ms * 1e-3, wall], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    wall_max, host_wall_max = float(tt[0].item()), float(tt[1].item())
+
+    def timed_windows(fn, windows):
+        """`windows` timed regions of exactly --steps launches each, every one bracketed by barrier + synchronize on both
+        sides and timed with HIP events on the launch stream (a host clock around a 0.15 ms region mostly measures the
+        closing synchronize).  Returns per-window (device seconds, host seconds), max over ranks."""
+        rows = []
+        for _ in range(windows):
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(stream)
+            for _ in range(args.steps):
+                fn()
+            e1.record(stream)
+            barrier()
+            rows.append((e0.elapsed_time(e1) * 1e-3, time.perf_counter() - t0))
+        tt = torch.tensor(rows, dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return tt.cpu().tolist()
+
+    def spread(vals):
+        v = sorted(vals)
+        return {"median": v[len(v) // 2], "min": v[0], "max": v[-1], "windows": len(v)}
+
+    win = timed_windows(step, args.windows)
+    dev_s = spread([w[0] for w in win])
+    host_s = spread([w[1] for w in win])
+    # headline = the MEDIAN window (each window = --steps launches between two barrier + synchronize brackets, max over ranks)
+    wall_max, host_wall_max = dev_s["median"], host_s["median"]
+    dev_ms = wall_max * 1e3
     mean_legal = float(count.float().mean().item())
 
     t_side0 = time.perf_counter()
@@ -600,16 +616,22 @@ def main():
         for _ in range(10):
             L.hive_movegen_launch(bp, n, mp, cp, lp, sp)
         torch.cuda.synchronize()
-        l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        l0.record(stream)
-        for _ in range(args.steps):
-            L.hive_movegen_launch(bp, n, mp, cp, lp, sp)
-        l1.record(stream)
-        torch.cuda.synchronize()
-        lms = l0.elapsed_time(l1) / args.steps
+        lwin = []
+        for _ in range(args.windows):
+            torch.cuda.synchronize()
+            l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            l0.record(stream)
+            for _ in range(args.steps):
+                L.hive_movegen_launch(bp, n, mp, cp, lp, sp)
+            l1.record(stream)
+            torch.cuda.synchronize()
+            lwin.append(l0.elapsed_time(l1) / args.steps)
+        lsp = spread(lwin)
+        lms = lsp["median"]
         with_list = {"Mboards_per_s": round(n / lms / 1e3, 2), "ms_per_step": round(lms, 6),
+                     "ms_per_step_min": round(lsp["min"], 6), "ms_per_step_max": round(lsp["max"], 6), "windows": lsp["windows"],
                      "note": "ONE launch: hive_piece_kernel<false, true> keeps the destination boards in LDS and its waves build the "
-                             "ascending int16 id lists (GamePlay.actions()) behind one barrier"}
+                             "ascending int16 id lists (GamePlay.actions()) behind one barrier; median of the windows"}
     # side measurement: the same 4096-board steps, independent batches issued round-robin on 4 HIP streams
     # (what a self-play engine with several game groups does); NOT the headline value
     overlapped = None
@@ -730,7 +752,11 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(wall_max * 1e3 / args.steps, 6),
-            "timing": "HIP events on the launch stream inside the barrier+synchronize brackets, max over ranks",
+            "ms_per_step_min": round(dev_s["min"] * 1e3 / args.steps, 6),
+            "ms_per_step_max": round(dev_s["max"] * 1e3 / args.steps, 6),
+            "windows": dev_s["windows"],
+            "timing": "median of `windows` timed regions of exactly `steps` launches each, every region between two barrier + "
+                      "synchronize brackets, HIP events on the launch stream, max over ranks per region; min / max = the spread",
             "host_wall_ms_per_step": round(host_wall_max * 1e3 / args.steps, 6),
             "higher_is_better": True,
             "scaling": "weak",

@@ -402,9 +402,19 @@ class InferenceNet:
     tower: 0 = one hive_nn_resblock_dt launch per residual block (default: measured fastest, profiles/r03_net_tower.md);
     1 / 2 / 3 = the whole tower in one hive_nn_tower launch (its boards_per_group modes; same bits)."""
 
-    def __init__(self, net, dtype=torch.bfloat16, device=None, use_graph=True, conv=None, tune_gemms=True, tower=0):
+    FP16_HEADROOM = 8.0                  # fp16 is chosen only while every probed magnitude stays below 65504 / 8
+
+    def __init__(self, net, dtype=None, device=None, use_graph=True, conv=None, tune_gemms=True, tower=0):
+        """dtype None = choose on measurement (api_hive.py:56-69 evaluates in fp32; fp16 reproduces its search in 100 % of
+        the test positions, bf16 in 97.7 %, tests/test_net.py): fp16 on a GPU when `range_probe` shows the BatchNorm-folded
+        weights and every layer's activations on a batch of playout positions at least FP16_HEADROOM below the fp16
+        maximum, else bf16 (whose exponent range is fp32's); fp32 on the CPU.  `precision_report` holds the numbers."""
         dev = torch.device(device) if device is not None else next(net.parameters()).device
+        auto = dtype is None
+        if auto:
+            dtype = torch.float16 if dev.type == "cuda" and conv in (None, "hip") else torch.float32
         self.device, self.dtype, self.use_graph = dev, dtype, use_graph and dev.type == "cuda"
+        self.precision_report = {"requested": "auto" if auto else str(dtype).replace("torch.", "")}
         hip_ok = dev.type == "cuda" and dtype in (torch.bfloat16, torch.float16)
         if conv is None:
             conv = "hip" if hip_ok else "torch"
@@ -426,6 +436,63 @@ class InferenceNet:
         self._tunable_before = None        # TunableOp's process-wide switch as it was before this object turned it on
         import threading
         self._lock = threading.Lock()      # capture/replay share static buffers: one caller at a time
+        if auto and self.dtype == torch.float16:
+            rep = self.range_probe()
+            self.precision_report.update(rep)
+            if not rep["fp16_safe"]:
+                # this checkpoint's folded weights / activations come within FP16_HEADROOM of the fp16 maximum (or beyond):
+                # re-fold in bf16, whose exponent range is fp32's
+                self.dtype = torch.bfloat16
+                for name, value in self._folded(net.eval()).items():
+                    setattr(self, name, value)
+        self.precision_report["dtype"] = str(self.dtype).replace("torch.", "")
+
+    @torch.no_grad()
+    def range_probe(self, planes_hwc=None, positions=64):
+        """Largest magnitudes the 16-bit engine meets: max |BatchNorm-folded weight| and, on one batch of positions (given,
+        or `positions` random-playout positions encoded by the env kernels), max |activation| after every convolution of
+        the tower (launch-per-convolution form, so the intermediate of a residual block is seen too) and in the heads.
+        An overflow shows as inf (the epilogues round to the 16-bit type without saturating).  fp16_safe = everything is
+        finite and below 65504 / FP16_HEADROOM."""
+        if self.conv != "hip":
+            raise ValueError("range_probe measures the 16-bit HIP engine")
+        import ctypes
+        from . import _lib, playout
+        dev = self.device
+        if planes_hwc is None:
+            boards = playout.random_positions(positions, seed=20260, device=dev.index)
+            n = boards.shape[0]
+            hist = torch.zeros((n, 384), dtype=torch.uint8, device=dev)
+            ws = torch.empty((n * 144,), dtype=torch.int64, device=dev)
+            planes_hwc = torch.empty((n, 12, 12, 56), dtype=self.dtype, device=dev)
+            P = lambda t: ctypes.c_void_p(t.data_ptr())
+            _lib.check(self._L.hive_encode_launch(P(boards), P(hist), n, P(planes_hwc), _lib.F16 if self.dtype == torch.float16 else _lib.BF16,
+                                                  _lib.HWC, P(ws), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        x = planes_hwc.to(self.dtype).contiguous()
+        B = x.shape[0]
+        wmax = max(float(t.float().abs().max()) for t in (self.h_stem[0], self.h_tower[0], self.pconv[0], self.vconv[0], self.fc[0]))
+        amax = []
+        bufs = [torch.zeros((B, 12, 12, 256), dtype=self.dtype, device=dev) for _ in range(3)]
+        s = self._conv_hip(x, 56, self.h_stem[0], self.h_stem[1], None, bufs[0])
+        amax.append(float(s.float().abs().max()))
+        cur = 0
+        for w1, b1, w2, b2 in self.h_blocks:
+            o = self._conv_hip(s, 256, w1, b1, None, bufs[(cur + 1) % 3])
+            amax.append(float(o.float().abs().max()))
+            s = self._conv_hip(o, 256, w2, b2, s, bufs[(cur + 2) % 3])
+            amax.append(float(s.float().abs().max()))
+            cur = (cur + 2) % 3
+        flat = s.reshape(B * 144, 256)
+        hp = F.relu(F.linear(flat, *self.pconv))
+        logits = F.linear(hp.reshape(B, 144 * 128), *self.fc)
+        hv = F.relu(F.linear(flat, *self.vconv))
+        heads = [float(t.float().abs().max()) for t in (hp, logits, hv)]
+        top = max([wmax] + amax + heads)
+        limit = 65504.0 / self.FP16_HEADROOM
+        import math
+        return {"probe_positions": int(B), "max_abs_folded_weight": wmax, "max_abs_activation_tower": max(amax),
+                "max_abs_activation_per_conv": [round(a, 3) for a in amax], "max_abs_heads": max(heads),
+                "fp16_limit_with_headroom": limit, "fp16_safe": bool(math.isfinite(top) and top < limit)}
 
     def _folded(self, net):
         """Every weight tensor of the forward, BatchNorm folded, in the layouts the kernels read."""
@@ -628,10 +695,15 @@ class InferenceNet:
             tn.tuning_enable(False)
 
     @property
+    def graph_batches(self):
+        """Batch sizes a HIP graph has been captured for (in the current or an earlier launch form)."""
+        return {k[0] for k in self._graphs}
+
+    @property
     def accepts_need(self):
         """__call__ honours the row selection of hive_search_leaf_need (mcts.TreeSearch asks): the HIP tower only -- the
         library path evaluates every row, and says so, so that the search's rows-evaluated counter stays true."""
-        return self.conv == "hip"
+        return self.conv == "hip" and self.tower == 0 and self.fuse_blocks
 
     accepts_rep = accepts_need   # ... and the representatives of equal rows (hive_leaf_dedup_launch)
 
@@ -641,7 +713,7 @@ class InferenceNet:
         rep: int32[B] or None -- equal rows (hive_leaf_dedup_launch): row i, switched off in `need`, gets the tower output
         of row rep[i] copied in before the heads, so its p / v are the bits it would have produced itself."""
         with self._lock:
-            hip = self.conv == "hip"
+            hip = self.accepts_need
             p, v = self._call_locked(planes_hwc, need if hip else None, rep if hip else None)
             return (p.clone(), v.clone()) if self.use_graph else (p, v)
 
@@ -652,7 +724,8 @@ class InferenceNet:
         if not self.use_graph:
             return self._forward(planes_hwc, need, rep)
         hip = self.conv == "hip"
-        g = self._graphs.get(B)
+        key = (B, self.tower, self.fuse_blocks, self.split_streams)      # a captured graph keeps the launch form it saw
+        g = self._graphs.get(key)
         if g is None:
             static_in = torch.zeros_like(planes_hwc)
             static_in.copy_(planes_hwc)
@@ -673,7 +746,7 @@ class InferenceNet:
                 if hip:
                     graph.replay()             # every board selected: the graph's activation buffers now hold finite rows
                 g = [graph, static_in, out, static_need, True, static_rep, True]
-                self._graphs[B] = g
+                self._graphs[key] = g
             finally:
                 if self._tunable_before is not None:
                     # TunableOp's switch is process-global: hand it back as it was -- also when tuning or the capture

@@ -497,7 +497,7 @@ def test_inference_net_refresh_keeps_graphs_and_takes_new_weights():
     graphs = dict(inf._graphs)
     inf.refresh(net_b)
     pb, vb = inf(x)
-    assert inf._graphs == graphs and 32 in inf._graphs          # no re-capture
+    assert inf._graphs == graphs and 32 in inf.graph_batches      # no re-capture
     fresh_p, fresh_v = InferenceNet(net_b)(x)
     assert torch.equal(pb, fresh_p) and torch.equal(vb, fresh_v)
     assert (pa - pb).abs().max().item() > 1e-5                  # and it is not the old network any more
@@ -506,7 +506,7 @@ def test_inference_net_refresh_keeps_graphs_and_takes_new_weights():
     was = tn.is_enabled()
     big = (torch.rand((256, 12, 12, 56), device="cuda") < 0.1).to(torch.bfloat16)
     p256, _ = inf(big)
-    assert tn.is_enabled() == was and 256 in inf._graphs
+    assert tn.is_enabled() == was and 256 in inf.graph_batches
     assert float((p256.sum(1) - 1).abs().max().item()) < 1e-3
 
 
