@@ -130,11 +130,15 @@ def selfplay_measure(args, rank, local_rank, world):
     from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
     torch.manual_seed(0)
     base = ChessNet().cuda().eval()
-    net_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.net_dtype]
-    net = InferenceNet(base, dtype=net_dtype)
+    # "auto" (default): InferenceNet measures the checkpoint's range and takes fp16 if it is safe, else bf16
+    net = InferenceNet(base, dtype={"auto": None, "bf16": torch.bfloat16, "fp16": torch.float16}[args.net_dtype])
+    net_dtype = net.dtype
+    dname = str(net_dtype).replace("torch.", "").replace("bfloat16", "bf16").replace("float16", "fp16")
     out = {"workload": f"selfplay_{args.games}x{args.sims}sims" + (f"_slots{args.slots}" if args.slots > 1 else ""),
-           "net": f"ChessNet 20-block ResNet, random init (torch.manual_seed(0)), {args.net_dtype} channels-last, HIP-graph replay"}
-    if rank == 0:
+           "net": f"ChessNet 20-block ResNet, random init (torch.manual_seed(0)), {dname} channels-last, HIP-graph replay",
+           "net_dtype": dname, "net_precision_choice": net.precision_report}
+    other = None
+    if rank == 0 and world == 1:                 # (N > 1: no rank-0-only legs while the other ranks wait at the all-reduce)
         # leaf-evaluator latency of the two 16-bit engines, interleaved (fp16: three more mantissa bits, same MFMA rate;
         # parity of both against the reference's fp32 outputs: tests/test_net.py::test_inference_net_wide_parity)
         other = InferenceNet(base, dtype=torch.float16 if net_dtype == torch.bfloat16 else torch.bfloat16)
@@ -157,7 +161,7 @@ def selfplay_measure(args, rank, local_rank, world):
         out["leaf_forward_ms"] = {"leaves": args.games * args.slots,
                                   str(net.dtype).replace("torch.", ""): round(med(lat[id(net)]), 4),
                                   str(other.dtype).replace("torch.", ""): round(med(lat[id(other)]), 4)}
-        del other, xs, x
+        del xs, x
 
     if args.whole_games:
         lo = rank * args.games                              # global game ids: rank r plays games r*G .. (r+1)*G - 1
@@ -166,8 +170,8 @@ def selfplay_measure(args, rank, local_rank, world):
         sp.play_ply()                                       # graph capture / GEMM tuning outside the timed region
         torch.cuda.synchronize()
         sp.close()
-        def whole_games_leg(search_options):
-            sp = mcts.SelfPlay(args.games, args.sims, net, device=local_rank, slots=args.slots, seed=1234, keep_records=False,
+        def whole_games_leg(search_options, evaluator=net):
+            sp = mcts.SelfPlay(args.games, args.sims, evaluator, device=local_rank, slots=args.slots, seed=1234, keep_records=False,
                                game_ids=range(lo, lo + args.games), search_options=search_options)
             torch.cuda.synchronize()
             ev0 = int(sp.search.evals_run.item())
@@ -201,7 +205,19 @@ def selfplay_measure(args, rank, local_rank, world):
                                                                            "leaf_batch", "leaf_rows_launched", "leaf_evals_executed",
                                                                            "roofline")}
         out["whole_games"] = whole
+        out["whole_games_" + dname] = {k: whole[k] for k in ("games", "wall_s", "games_per_min", "ms_per_ply", "results", "roofline")}
         out["games_per_min"] = whole["games_per_min"]
+        if other is not None and args.both_dtypes:
+            # the same 1024 games (same seed, same ids) through the OTHER 16-bit engine: M1 at both precisions
+            oname = "bf16" if dname == "fp16" else "fp16"
+            sp = mcts.SelfPlay(args.games, args.sims, other, device=local_rank, slots=args.slots, seed=1234, keep_records=False,
+                               game_ids=range(lo, lo + args.games))
+            sp.play_ply()                                       # graph capture of this engine outside the timed region
+            torch.cuda.synchronize()
+            sp.close()
+            o = whole_games_leg(None, other)
+            out["whole_games_" + oname] = {k: o[k] for k in ("games", "wall_s", "games_per_min", "ms_per_ply", "results", "roofline")}
+    other = None
 
     if args.whole_games and args.records:
         # the same whole games with the per-ply records ON (woker/self_play.py:159-160: a row per ply; :178-193 values at the
@@ -265,6 +281,9 @@ def selfplay_measure(args, rank, local_rank, world):
         steady.update(_leaf_accounting(hist, launched, executed, el))
         sp.close()
         out["steady_state"] = steady
+        # what a long run sustains (finished games replaced at once, games spread over all plies): the figure to quote;
+        # `games_per_min` beside it is BASELINE configs[2] literally (1024 games from the opening, lock step, records on)
+        out["games_per_min_steady_state"] = steady["games_per_min_counted"]
         out.setdefault("games_per_min", steady["games_per_min_counted"])
         out["leaf_evals_per_s"] = round(executed / el, 1)
     del net
@@ -276,7 +295,7 @@ def selfplay_measure(args, rank, local_rank, world):
     return out
 
 
-def selfplay_worker_measure(args, local_rank):
+def selfplay_worker_measure(args, local_rank, gpus=None):
     """M1 as the PRODUCER the reference's woker/self_play.py is (:37-75 pool, :100-112 files): SelfPlayWorker spawns one
     child for this GPU, the child builds the network and the engine, plays `games` whole games with records on and sends
     every finished game through the queue; the parent writes compact play_<ts>.npz files.  Timed from the spawn to the
@@ -287,20 +306,24 @@ def selfplay_worker_measure(args, local_rank):
     from hive_alphazero_amd.self_play import SelfPlayWorker
     d = tempfile.mkdtemp(prefix="hive_bench_selfplay_")
     try:
-        w = SelfPlayWorker(total_games=args.games, games_per_gpu=args.games, sims=args.sims, gpus=[local_rank], seed=1234,
+        gpus = [local_rank] if gpus is None else list(gpus)
+        w = SelfPlayWorker(total_games=args.games * len(gpus), games_per_gpu=args.games, sims=args.sims, gpus=gpus, seed=1234,
                            slots=args.slots, datapath=d, games_per_file=256, report_every=0, row_format="compact",
-                           log=lambda *_: None, warmup=True, net_dtype=args.net_dtype)
+                           log=lambda *_: None, warmup=True, net_dtype=args.net_dtype, keep_results=False)
         t0 = time.time()
         res = w.start(timeout_s=900)
         t1 = time.time()
-        ready = w.ready_at.get(0, t0)
+        # playing time runs from the LAST child's "ready" (every GPU has its network and engine) to the last flushed file
+        ready = max(w.ready_at.values()) if w.ready_at else t0
         files = [os.path.getsize(f) for f in w.files]
         rows = int(sum(w.game_lens))
-        return {"games": len(res), "rows": rows, "files": len(files), "file_bytes": int(sum(files)),
+        return {"gpus": len(gpus), "games": len(res), "rows": rows, "files": len(files), "file_bytes": int(sum(files)),
                 "wall_s_total": round(t1 - t0, 3), "child_startup_s": round(ready - t0, 3),
+                "child_ready_s_per_rank": {str(r): round(t - t0, 3) for r, t in sorted(w.ready_at.items())},
                 "wall_s_playing": round(t1 - ready, 3),
                 "games_per_min_playing": round(len(res) / max(t1 - ready, 1e-9) * 60.0, 2),
                 "games_per_min_total": round(len(res) / (t1 - t0) * 60.0, 2),
+                "parent": w.parent_stats, "net_dtype": {str(r): p.get("dtype") for r, p in sorted(w.precision.items())},
                 "row_format": "compact (.npz of packed features + sparse policies; records.rows_from_game expands to the "
                               "reference's JSON rows)",
                 "note": "child_startup_s = interpreter + import torch + network + engine + one warm-up ply (graph capture, "
@@ -513,7 +536,10 @@ def main():
                     "concurrent launches stretch the per-kernel durations rocprof reports)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
                     "the multi-rank path on a single GPU")
-    ap.add_argument("--net-dtype", default="bf16", choices=["bf16", "fp16"], help="leaf-evaluator precision of the self-play legs")
+    ap.add_argument("--net-dtype", default="auto", choices=["auto", "bf16", "fp16"],
+                    help="leaf-evaluator precision of the self-play legs (auto: fp16 if InferenceNet's range probe passes, else bf16)")
+    ap.add_argument("--no-both-dtypes", dest="both_dtypes", action="store_false",
+                    help="skip the whole-games leg at the other 16-bit precision")
     ap.add_argument("--no-every-row", dest="every_row", action="store_false",
                     help="skip the whole-games leg that evaluates every launched row (no row skipping, no shared leaves)")
     ap.add_argument("--no-records", dest="records", action="store_false", help="skip the records-on whole-game self-play leg")
@@ -607,6 +633,40 @@ def main():
     mean_legal = float(count.float().mean().item())
 
     t_side0 = time.perf_counter()
+    selfplay = None
+    if args.selfplay_plies > 0 or args.whole_games:
+        try:
+            selfplay = selfplay_measure(args, rank, local_rank, world)
+        except Exception as exc:                 # the headline line must still come out
+            selfplay = {"error": repr(exc), "games_per_min": 0.0, "leaf_evals_per_s": 0.0}
+        if world > 1:
+            t = torch.tensor([selfplay.get("games_per_min", 0.0), selfplay.get("leaf_evals_per_s", 0.0)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            selfplay["games_per_min_all_gpus"] = round(float(t[0].item()), 2)
+            selfplay["leaf_evals_per_s_all_gpus"] = round(float(t[1].item()), 1)
+
+    # the PRODUCER on all N GPUs as one thing (woker/self_play.py:37-75,100-112: ONE parent gathers every game and writes the
+    # files): rank 0 drives SelfPlayWorker(gpus = every rank's GPU) while the ranks -- their engines closed, their memory
+    # released -- wait on the rendezvous store (a host-side wait: no collective kernel spins on the GPUs meanwhile)
+    if world > 1 and args.worker and args.whole_games and selfplay is not None and "error" not in selfplay:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        dist.barrier()
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            try:
+                ndev = torch.cuda.device_count()
+                selfplay["producer_selfplay_worker_all_gpus"] = selfplay_worker_measure(args, local_rank,
+                                                                                        gpus=[r % ndev for r in range(world)])
+            except Exception as exc:
+                selfplay["producer_selfplay_worker_all_gpus"] = {"error": repr(exc)}
+            store.set("hive_bench_producer_done", "1")
+        else:
+            import datetime
+            store.wait(["hive_bench_producer_done"], datetime.timedelta(seconds=1800))
+
     # side measurement: legal set AND its compaction into sorted action ids (GamePlay.encode_action, env_hive.py:287-304)
     # -- what GamePlay.actions() returns -- by the fused launch
     with_list = None
@@ -716,18 +776,6 @@ def main():
             encode = encode_measure(L, args.encode_boards)
         except Exception as exc:
             encode = {"error": repr(exc)}
-
-    selfplay = None
-    if args.selfplay_plies > 0 or args.whole_games:
-        try:
-            selfplay = selfplay_measure(args, rank, local_rank, world)
-        except Exception as exc:                 # the headline line must still come out
-            selfplay = {"error": repr(exc), "games_per_min": 0.0, "leaf_evals_per_s": 0.0}
-        if world > 1:
-            t = torch.tensor([selfplay.get("games_per_min", 0.0), selfplay.get("leaf_evals_per_s", 0.0)], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            selfplay["games_per_min_all_gpus"] = round(float(t[0].item()), 2)
-            selfplay["leaf_evals_per_s_all_gpus"] = round(float(t[1].item()), 1)
 
     training = None
     if world == 1 and args.train_steps > 0:                   # single-GPU side measurement (no DDP group to join)

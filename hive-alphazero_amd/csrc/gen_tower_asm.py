@@ -1,0 +1,565 @@
+#!/usr/bin/env python3
+"""gen_tower_asm.py -- writes the gfx950 assembly of `hive_tower72_{bf16,f16}`: the residual tower of the leaf evaluator
+(alpha_net.py:36-54,87-99 of the reference: y = relu(conv2(relu(conv1(x) + b1)) + b2 + x), nblocks times) with a 72-tile
+wave -- what hipcc cannot allocate (288 accumulator registers across the AGPR / VGPR halves, profiles/r03_net_tower.md).
+
+Shape (one workgroup = 4 waves = one wave per SIMD = TWO boards):
+  * both boards (2 x 144 pixels x 256 channels, 16-bit) live in LDS for the whole tower, pixel stride 544 B, plus a zero
+    pixel that every off-board tap reads (157,216 B of the CU's 160 KB);
+  * wave w owns output channels 64 w .. 64 w + 63 (4 M tiles) of BOTH boards' 288 pixels (18 N tiles): 72 accumulator
+    tiles = a[0:255] + v[..] -- every weight fragment fetched from L2 feeds two boards (half the weight stream per MFMA
+    of the one-board kernels, 0.31 instead of 0.36 KiB of operands per MFMA);
+  * weights (fragment-major, hive_nn.h) go L2 -> VGPR three k-steps ahead through a ring of four 4-fragment buffers; the
+    pixel fragments come from LDS five reads ahead through a ring of six; the 8 k-steps of a tap are unrolled, every LDS
+    offset is an immediate, the per-tap pixel offsets (off-board -> zero pixel) come from a table in .rodata;
+  * arithmetic and rounding points are exactly those of resblock_kernel / tower_kernel (hive_nn.hip): fp32 accumulation
+    in k order, (acc + bias) [+ skip], max(0, .), one rounding to 16 bits -- the results are bit-identical.
+
+The generator keeps a model of the two in-order memory queues (vmcnt / lgkmcnt) and derives every s_waitcnt from it.
+
+usage: gen_tower_asm.py out.s
+"""
+import sys
+
+PS = 544                      # LDS pixel stride in bytes (34 sixteen-byte slots: the 16 lanes of a ds_read_b128 phase hit 16 slots)
+NT, MT = 18, 4                # pixel tiles (both boards) x channel tiles per wave
+ZOFF = 288 * PS               # the zero pixel
+LDS_BYTES = 289 * PS
+D = 5                         # B-fragment LDS reads in flight
+BRING = 6                     # ring of B-fragment buffers
+ARING, AD = 4, 3              # ring of weight buffers; k-steps the weights are fetched ahead
+ROW_BYTES = 144 * 256 * 2     # one board in global memory
+KSTEP_BYTES = 16 * 1024       # one k-step of packed weights (16 fragments of 1 KiB)
+
+# ---- register map -------------------------------------------------------------------------------------------------
+V_TID = 0
+V_WLANE = 1                   # wave * 4096 + lane * 16: this lane's byte offset inside a k-step's fragments
+V_TAB = 2                     # lane * 4
+V_BOFF = 3                    # 18: LDS byte offset of this lane's fragment row of pixel tile nt under the current tap
+V_BOFFN = V_BOFF + NT         # 18: ... under the next tap
+V_A = V_BOFFN + NT            # 64: weight ring [ARING][MT][4]
+V_B = V_A + ARING * MT * 4    # 24: pixel-fragment ring [BRING][4]
+V_ACC = V_B + BRING * 4       # 32: accumulator tiles 64..71
+V_BIAS = V_ACC + 32           # 16: bias[mt][4]
+V_T = V_BIAS + 16             # 36: epilogue temporaries (3 sets of 12)
+V_SK = V_T + 36               # 32: skip operands in flight (4 batches x 4 tiles x 2)
+V_GO = V_SK + 32              # 4: global pixel offsets of the batches in flight
+V_LDSW = V_GO + 4             # 3: epilogue LDS write bases
+V_GOFF = V_LDSW + 3           # 1: lr * 512 + lg * 8 + wave * 128
+V_BIASOFF = V_GOFF + 1        # 1: wave * 256 + lg * 16
+V_TMP = V_BIASOFF + 1         # 4 scratch
+V_END = V_TMP + 4
+assert V_END <= 256, V_END
+NEXT_VGPR = (V_END + 7) // 8 * 8
+V_STAGE = V_A                 # 144 registers of staging data (prologue only; everything above V_A is dead then)
+assert V_STAGE + 144 <= 256
+
+S_KARG = 0
+S_WG = 2
+S_X, S_W, S_BIAS, S_Y, S_IDX, S_CNT = 4, 6, 8, 10, 12, 14
+S_N, S_NBLK = 16, 17
+S_SKIP0, S_SKIP1 = 20, 22     # skip operand rows (X for the first block, then Y)
+S_Y0, S_Y1 = 24, 26
+S_WP = 28                     # weight prefetch pointer (k-step current + AD)
+S_WLEFT = 30                  # advances of S_WP still allowed
+S_T0 = 31
+S_BP = 32                     # bias of the current block's conv1
+S_TAP = 34
+S_BLK = 35
+S_TAB = 36                    # table + 2048
+S_TP = 38                     # table pointer of the tap whose offsets are fetched next (+2048)
+S_WAVE = 40
+S_R0, S_R1 = 41, 42
+S_T1, S_T2, S_T3 = 43, 44, 45
+S_SRC = 46                    # pair: staging source
+NEXT_SGPR = 56
+
+
+def acc_reg(t):
+    """Register range of accumulator tile t = nt * 4 + mt."""
+    return "a[%d:%d]" % (4 * t, 4 * t + 3) if t < 64 else "v[%d:%d]" % (V_ACC + 4 * (t - 64), V_ACC + 4 * (t - 64) + 3)
+
+
+def vr(base, n=1):
+    return "v%d" % base if n == 1 else "v[%d:%d]" % (base, base + n - 1)
+
+
+def sr(base, n=1):
+    return "s%d" % base if n == 1 else "s[%d:%d]" % (base, base + n - 1)
+
+
+class Asm:
+    def __init__(self):
+        self.lines = []
+        self.vm_q, self.lg_q = [], []          # outstanding tags, oldest first
+
+    def e(self, s):
+        self.lines.append("\t" + s)
+
+    def label(self, s):
+        self.lines.append(s + ":")
+
+    def comment(self, s):
+        self.lines.append("\t; " + s)
+
+    # ---- queue model
+    def vm(self, text, tag):
+        self.e(text)
+        self.vm_q.append(tag)
+
+    def lg(self, text, tag):
+        self.e(text)
+        self.lg_q.append(tag)
+
+    def wait(self, vm_tag=None, lg_tag=None):
+        """Wait until the operations tagged vm_tag / lg_tag (and everything older) have completed."""
+        parts = []
+        if vm_tag is not None and vm_tag in self.vm_q:
+            i = self.vm_q.index(vm_tag)
+            n = len(self.vm_q) - 1 - i
+            assert n <= 63, n
+            parts.append("vmcnt(%d)" % n)
+            self.vm_q = self.vm_q[i + 1:]
+        if lg_tag is not None and lg_tag in self.lg_q:
+            i = self.lg_q.index(lg_tag)
+            n = len(self.lg_q) - 1 - i
+            assert n <= 15, n
+            parts.append("lgkmcnt(%d)" % n)
+            self.lg_q = self.lg_q[i + 1:]
+        if parts:
+            self.e("s_waitcnt " + " ".join(parts))
+
+    def drain(self, vm=True, lg=True):
+        parts = []
+        if vm:
+            parts.append("vmcnt(0)")
+            self.vm_q = []
+        if lg:
+            parts.append("lgkmcnt(0)")
+            self.lg_q = []
+        self.e("s_waitcnt " + " ".join(parts))
+
+
+def tap_table():
+    """tab[tap][nt][lane]: LDS byte offset of lane's B-fragment row (pixel nt*16 + lane%16 shifted by the tap, k-group lane/16)."""
+    out = []
+    for tap in range(9):
+        dy, dx = tap // 3 - 1, tap % 3 - 1
+        for nt in range(NT):
+            slot, pt = divmod(nt, 9)
+            for lane in range(64):
+                lr, lg = lane & 15, lane >> 4
+                pixel = pt * 16 + lr
+                y0, x0 = divmod(pixel, 12)
+                sy, sx = y0 + dy, x0 + dx
+                inb = 0 <= sy < 12 and 0 <= sx < 12
+                out.append(((slot * 144 + sy * 12 + sx) * PS if inb else ZOFF) + lg * 16)
+    return out
+
+
+def gen_kernel(name, dt, debug=0):
+    """dt: 'bf16' or 'f16'."""
+    A = Asm()
+    mfma = "v_mfma_f32_16x16x32_" + dt
+    cvt = "v_cvt_pk_bf16_f32" if dt == "bf16" else "v_cvt_pk_f16_f32"
+    e, c = A.e, A.comment
+
+    # =============================================================== prologue
+    c("kernarg: X W bias Y idx count | batch nblocks")
+    e("s_load_dwordx8 %s, %s, 0x0" % (sr(S_X, 8), sr(S_KARG, 2)))
+    e("s_load_dwordx4 %s, %s, 0x20" % (sr(S_IDX, 4), sr(S_KARG, 2)))
+    e("s_load_dwordx2 %s, %s, 0x30" % (sr(S_N, 2), sr(S_KARG, 2)))
+    e("v_lshrrev_b32_e32 %s, 6, %s" % (vr(V_TMP), vr(V_TID)))
+    e("v_readfirstlane_b32 %s, %s" % (sr(S_WAVE), vr(V_TMP)))
+    e("s_waitcnt lgkmcnt(0)")
+    c("n = count ? *count : batch")
+    e("s_cmp_eq_u64 %s, 0" % sr(S_CNT, 2))
+    e("s_cbranch_scc1 .L%s_havecount" % name)
+    e("s_load_dword %s, %s, 0x0" % (sr(S_N), sr(S_CNT, 2)))
+    e("s_waitcnt lgkmcnt(0)")
+    A.label(".L%s_havecount" % name)
+    e("s_lshl_b32 %s, %s, 1" % (sr(S_R0), sr(S_WG)))
+    e("s_cmp_ge_u32 %s, %s" % (sr(S_R0), sr(S_N)))
+    e("s_cbranch_scc1 .L%s_end" % name)
+    c("second entry of the pair; an odd tail repeats the first (both halves then compute and store identical values)")
+    e("s_add_u32 %s, %s, 1" % (sr(S_R1), sr(S_R0)))
+    e("s_cmp_ge_u32 %s, %s" % (sr(S_R1), sr(S_N)))
+    e("s_cselect_b32 %s, %s, %s" % (sr(S_R1), sr(S_R0), sr(S_R1)))
+    e("s_cmp_eq_u64 %s, 0" % sr(S_IDX, 2))
+    e("s_cbranch_scc1 .L%s_rows" % name)
+    e("s_lshl_b32 %s, %s, 2" % (sr(S_T1), sr(S_R0)))
+    e("s_lshl_b32 %s, %s, 2" % (sr(S_T2), sr(S_R1)))
+    e("s_load_dword %s, %s, %s" % (sr(S_R0), sr(S_IDX, 2), sr(S_T1)))
+    e("s_load_dword %s, %s, %s" % (sr(S_R1), sr(S_IDX, 2), sr(S_T2)))
+    e("s_waitcnt lgkmcnt(0)")
+    A.label(".L%s_rows" % name)
+    c("row byte offsets (64 bit) -> skip (= X) and Y bases of the two boards")
+    for r, skip, yb in ((S_R0, S_SKIP0, S_Y0), (S_R1, S_SKIP1, S_Y1)):
+        e("s_mul_hi_u32 %s, %s, 0x%x" % (sr(S_T2), sr(r), ROW_BYTES))
+        e("s_mul_i32 %s, %s, 0x%x" % (sr(S_T1), sr(r), ROW_BYTES))
+        e("s_add_u32 %s, %s, %s" % (sr(skip), sr(S_X), sr(S_T1)))
+        e("s_addc_u32 %s, %s, %s" % (sr(skip + 1), sr(S_X + 1), sr(S_T2)))
+        e("s_add_u32 %s, %s, %s" % (sr(yb), sr(S_Y), sr(S_T1)))
+        e("s_addc_u32 %s, %s, %s" % (sr(yb + 1), sr(S_Y + 1), sr(S_T2)))
+
+    c("lane constants")
+    LANE, LR, LG = V_TMP + 1, V_TMP + 2, V_TMP + 3
+    e("v_and_b32_e32 %s, 63, %s" % (vr(LANE), vr(V_TID)))
+    e("v_and_b32_e32 %s, 15, %s" % (vr(LR), vr(V_TID)))
+    e("v_bfe_u32 %s, %s, 4, 2" % (vr(LG), vr(V_TID)))
+    e("v_lshlrev_b32_e32 %s, 2, %s" % (vr(V_TAB), vr(LANE)))
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(V_WLANE), vr(LANE)))
+    e("s_lshl_b32 %s, %s, 12" % (sr(S_T1), sr(S_WAVE)))
+    e("v_add_u32_e32 %s, %s, %s" % (vr(V_WLANE), sr(S_T1), vr(V_WLANE)))
+    e("s_lshl_b32 %s, %s, 7" % (sr(S_T1), sr(S_WAVE)))                    # wave * 128
+    e("v_lshlrev_b32_e32 %s, 3, %s" % (vr(V_TMP), vr(LG)))               # lg * 8
+    e("v_add_u32_e32 %s, %s, %s" % (vr(V_TMP), sr(S_T1), vr(V_TMP)))      # wave*128 + lg*8
+    e("v_mul_u32_u24_e32 %s, 0x%x, %s" % (vr(V_LDSW), PS, vr(LR)))
+    e("v_add_u32_e32 %s, %s, %s" % (vr(V_LDSW), vr(V_LDSW), vr(V_TMP)))
+    e("v_add_u32_e32 %s, 0x%x, %s" % (vr(V_LDSW + 1), 7 * 16 * PS, vr(V_LDSW)))
+    e("v_add_u32_e32 %s, 0x%x, %s" % (vr(V_LDSW + 2), 14 * 16 * PS, vr(V_LDSW)))
+    e("v_lshlrev_b32_e32 %s, 9, %s" % (vr(V_GOFF), vr(LR)))
+    e("v_add_u32_e32 %s, %s, %s" % (vr(V_GOFF), vr(V_GOFF), vr(V_TMP)))
+    e("s_lshl_b32 %s, %s, 8" % (sr(S_T1), sr(S_WAVE)))                    # wave * 256
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(V_BIASOFF), vr(LG)))
+    e("v_add_u32_e32 %s, %s, %s" % (vr(V_BIASOFF), sr(S_T1), vr(V_BIASOFF)))
+
+    c("table of tap offsets (.rodata of this code object), biased by 2048 so that 18 rows fit the 13-bit offsets")
+    e("s_getpc_b64 %s" % sr(S_TAB, 2))
+    e("s_add_u32 %s, %s, hive_tap_table@rel32@lo+2052" % (sr(S_TAB), sr(S_TAB)))
+    e("s_addc_u32 %s, %s, hive_tap_table@rel32@hi+2060" % (sr(S_TAB + 1), sr(S_TAB + 1)))
+
+    c("stage both boards: 36 sixteen-byte loads per thread, all in flight, then 36 LDS writes")
+    ST_ADDR, ST_G = V_BOFF, V_BOFF + 1          # (V_BOFF.. are dead until the first convolution)
+    e("v_lshrrev_b32_e32 %s, 5, %s" % (vr(ST_ADDR), vr(V_TID)))
+    e("v_mul_u32_u24_e32 %s, 0x%x, %s" % (vr(ST_ADDR), PS, vr(ST_ADDR)))
+    e("v_and_b32_e32 %s, 31, %s" % (vr(V_TMP), vr(V_TID)))
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(V_TMP), vr(V_TMP)))
+    e("v_add_u32_e32 %s, %s, %s" % (vr(ST_ADDR), vr(ST_ADDR), vr(V_TMP)))
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(ST_G), vr(V_TID)))
+    for s_, base in ((0, S_SKIP0), (1, S_SKIP1)):
+        e("s_mov_b64 %s, %s" % (sr(S_SRC, 2), sr(base, 2)))
+        for j in range(18):
+            k = s_ * 18 + j
+            A.vm("global_load_dwordx4 %s, %s, %s" % (vr(V_STAGE + 4 * k, 4), vr(ST_G), sr(S_SRC, 2)), ("stage", k))
+            if j < 17:
+                e("s_add_u32 %s, %s, 0x1000" % (sr(S_SRC), sr(S_SRC)))
+                e("s_addc_u32 %s, %s, 0" % (sr(S_SRC + 1), sr(S_SRC + 1)))
+    c("zero pixel (threads 0..33; the others repeat the last slot) and the accumulators while the loads fly")
+    e("v_min_u32_e32 %s, 33, %s" % (vr(V_TMP), vr(V_TID)))
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(V_TMP), vr(V_TMP)))
+    e("v_add_u32_e32 %s, 0x%x, %s" % (vr(V_TMP), ZOFF, vr(V_TMP)))
+    Z = V_TAB + 0  # placeholder (unused)
+    ZR = V_BOFF + 4                              # four zero registers (dead range)
+    for i in range(4):
+        e("v_mov_b32_e32 %s, 0" % vr(ZR + i))
+    A.lg("ds_write_b128 %s, %s" % (vr(V_TMP), vr(ZR, 4)), ("zero",))
+    for i in range(256):
+        e("v_accvgpr_write_b32 a%d, 0" % i)
+    for k in range(36):
+        s_, j = divmod(k, 18)
+        cst = (8 * j + 144 * s_) * PS
+        hi, lo = cst // 32768 * 32768, cst % 32768
+        addr = vr(ST_ADDR)
+        if hi:
+            e("v_add_u32_e32 %s, 0x%x, %s" % (vr(V_TMP + 1), hi, vr(ST_ADDR)))
+            addr = vr(V_TMP + 1)
+        A.wait(vm_tag=("stage", k))
+        A.lg("ds_write_b128 %s, %s offset:%d" % (addr, vr(V_STAGE + 4 * k, 4), lo), ("stw", k))
+        if len(A.lg_q) > 12:
+            A.wait(lg_tag=A.lg_q[-8])
+    for i in range(32):                          # (after the staging data has left these registers)
+        e("v_mov_b32_e32 %s, 0" % vr(V_ACC + i))
+
+    if debug == 1:
+        c("DEBUG 1: copy the LDS image back out (identity) and stop")
+        A.drain()
+        e("s_barrier")
+        for s_, base in ((0, S_Y0), (1, S_Y1)):
+            e("s_mov_b64 %s, %s" % (sr(S_SRC, 2), sr(base, 2)))
+            for j in range(18):
+                cst = (8 * j + 144 * s_) * PS
+                hi, lo = cst // 32768 * 32768, cst % 32768
+                addr = vr(ST_ADDR)
+                if hi:
+                    e("v_add_u32_e32 %s, 0x%x, %s" % (vr(V_TMP + 1), hi, vr(ST_ADDR)))
+                    addr = vr(V_TMP + 1)
+                e("ds_read_b128 %s, %s offset:%d" % (vr(V_STAGE, 4), addr, lo))
+                e("s_waitcnt lgkmcnt(0)")
+                e("global_store_dwordx4 %s, %s, %s" % (vr(ST_G), vr(V_STAGE, 4), sr(S_SRC, 2)))
+                e("s_nop 1")
+                e("s_add_u32 %s, %s, 0x1000" % (sr(S_SRC), sr(S_SRC)))
+                e("s_addc_u32 %s, %s, 0" % (sr(S_SRC + 1), sr(S_SRC + 1)))
+        e("s_waitcnt vmcnt(0)")
+        e("s_endpgm")
+        A.label(".L%s_end" % name)
+        e("s_endpgm")
+        return A.lines
+
+    c("weights: k-steps 0 .. AD-1 into ring buffers 0 .. AD-1; S_WP -> k-step AD; S_WLEFT = total k-steps - 1 - AD")
+    e("s_mov_b64 %s, %s" % (sr(S_WP, 2), sr(S_W, 2)))
+    for j in range(AD):
+        for mt in range(MT):
+            A.vm("global_load_dwordx4 %s, %s, %s offset:%d" % (vr(V_A + (j * MT + mt) * 4, 4), vr(V_WLANE), sr(S_WP, 2), mt * 1024),
+                 ("A0", j, mt))
+        e("s_add_u32 %s, %s, 0x%x" % (sr(S_WP), sr(S_WP), KSTEP_BYTES))
+        e("s_addc_u32 %s, %s, 0" % (sr(S_WP + 1), sr(S_WP + 1)))
+    e("s_mul_i32 %s, %s, 144" % (sr(S_WLEFT), sr(S_NBLK)))
+    e("s_sub_u32 %s, %s, %d" % (sr(S_WLEFT), sr(S_WLEFT), AD + 1))
+    e("s_mov_b64 %s, %s" % (sr(S_BP, 2), sr(S_BIAS, 2)))
+    e("s_mov_b32 %s, %s" % (sr(S_BLK), sr(S_NBLK)))
+    A.drain()
+    e("s_barrier")
+
+    # =============================================================== one convolution
+    def conv(tag):
+        c("---- convolution %s: 9 taps x 8 k-steps x (18 pixel tiles x 4 channel tiles)" % tag)
+        T = Asm()                                # the tap body is generated in its steady state
+        T.lines = A.lines
+        c("tap 0 offsets -> boff; table pointer -> tap 1")
+        for nt in range(NT):
+            A.vm("global_load_dword %s, %s, %s offset:%d" % (vr(V_BOFF + nt), vr(V_TAB), sr(S_TAB, 2), nt * 256 - 2048), ("T0", nt))
+        e("s_add_u32 %s, %s, 0x%x" % (sr(S_TP), sr(S_TAB), NT * 256))
+        e("s_addc_u32 %s, %s, 0" % (sr(S_TP + 1), sr(S_TAB + 1)))
+        e("s_mov_b32 %s, 0" % sr(S_TAP))
+        A.drain(vm=True, lg=False)
+        for g in range(D):
+            A.lg("ds_read_b128 %s, %s" % (vr(V_B + (g % BRING) * 4, 4), vr(V_BOFF + g)), ("B", g))
+        A.label(".L%s_%s_tap" % (name, tag))
+        T.vm_q = [("A", j, mt) for j in range(AD) for mt in range(MT)]
+        T.lg_q = [("B", g) for g in range(D)]
+        for f in range(8 * NT):
+            kc, nt = divmod(f, NT)
+            if nt == 0:
+                T.wait(vm_tag=("A", kc, MT - 1))
+            g = f + D
+            kcg, ntg = divmod(g, NT)
+            if kcg == 8:
+                pass                                 # (boff[ntg] already holds the next tap's offset: moved after read (7, ntg))
+            T.lg("ds_read_b128 %s, %s%s" % (vr(V_B + (g % BRING) * 4, 4), vr(V_BOFF + ntg),
+                                            " offset:%d" % ((kcg % 8) * 64) if kcg % 8 else ""), ("B", g))
+            if kcg == 7:
+                T.wait(vm_tag=("T", ntg))
+                T.e("v_mov_b32_e32 %s, %s" % (vr(V_BOFF + ntg), vr(V_BOFFN + ntg)))
+            T.wait(lg_tag=("B", f))
+            for mt in range(MT):
+                t = nt * MT + mt
+                T.e("%s %s, %s, %s, %s" % (mfma, acc_reg(t), vr(V_A + ((kc % ARING) * MT + mt) * 4, 4),
+                                             vr(V_B + (f % BRING) * 4, 4), acc_reg(t)))
+                if kc == 0 and mt == 1:
+                    T.vm("global_load_dword %s, %s, %s offset:%d" % (vr(V_BOFFN + nt), vr(V_TAB), sr(S_TP, 2), nt * 256 - 2048),
+                         ("T", nt))
+                if nt in (2, 6, 10, 14) and mt == 2:
+                    m = (nt - 2) // 4
+                    T.vm("global_load_dwordx4 %s, %s, %s offset:%d" % (vr(V_A + (((kc + AD) % ARING) * MT + m) * 4, 4), vr(V_WLANE),
+                                                                      sr(S_WP, 2), m * 1024), ("A", kc + AD, m))
+            if nt == 16:
+                c("advance the weight pointer by one k-step unless it already points at the last one")
+                T.e("s_cmp_lg_u32 %s, 0" % sr(S_WLEFT))
+                T.e("s_cselect_b32 %s, 0x%x, 0" % (sr(S_T0), KSTEP_BYTES))
+                T.e("s_cselect_b32 %s, 1, 0" % sr(S_T1))
+                T.e("s_add_u32 %s, %s, %s" % (sr(S_WP), sr(S_WP), sr(S_T0)))
+                T.e("s_addc_u32 %s, %s, 0" % (sr(S_WP + 1), sr(S_WP + 1)))
+                T.e("s_sub_u32 %s, %s, %s" % (sr(S_WLEFT), sr(S_WLEFT), sr(S_T1)))
+        # steady state reached again?
+        assert T.vm_q == [("A", 8 + j, mt) for j in range(AD) for mt in range(MT)], T.vm_q
+        assert T.lg_q == [("B", 8 * NT + g) for g in range(D)], T.lg_q
+        c("next tap: table pointer (wraps to tap 0 after the last one: those offsets are fetched and never used)")
+        e("s_add_u32 %s, %s, 1" % (sr(S_TAP), sr(S_TAP)))
+        e("s_add_u32 %s, %s, 0x%x" % (sr(S_TP), sr(S_TP), NT * 256))
+        e("s_addc_u32 %s, %s, 0" % (sr(S_TP + 1), sr(S_TP + 1)))
+        e("s_cmp_eq_u32 %s, 8" % sr(S_TAP))
+        e("s_cselect_b32 %s, %s, %s" % (sr(S_TP), sr(S_TAB), sr(S_TP)))
+        e("s_cselect_b32 %s, %s, %s" % (sr(S_TP + 1), sr(S_TAB + 1), sr(S_TP + 1)))
+        e("s_cmp_lt_u32 %s, 9" % sr(S_TAP))
+        e("s_cbranch_scc1 .L%s_%s_tap" % (name, tag))
+        c("drain the stray fragment reads, let the last MFMAs retire")
+        e("s_waitcnt lgkmcnt(0)")
+        for _ in range(3):
+            e("s_nop 7")
+        A.vm_q, A.lg_q = [], []                      # (the A prefetches in flight are drained by the epilogue's vmcnt(0))
+
+    def tile_src(t, tmp):
+        """Accumulator tile t -> four consecutive VGPRs holding it (reads AGPR tiles into tmp and re-zeroes the tile)."""
+        if t < 64:
+            for i in range(4):
+                e("v_accvgpr_read_b32 %s, a%d" % (vr(tmp + i), 4 * t + i))
+            for i in range(4):
+                e("v_accvgpr_write_b32 a%d, 0" % (4 * t + i))
+            return tmp, False
+        return V_ACC + 4 * (t - 64), True
+
+    def bias_loads(extra):
+        for mt in range(MT):
+            A.vm("global_load_dwordx4 %s, %s, %s offset:%d" % (vr(V_BIAS + 4 * mt, 4), vr(V_BIASOFF), sr(S_BP, 2), mt * 64 + extra),
+                 ("bias", mt))
+
+    A.label(".L%s_block" % name)
+    # =============================================================== conv1 + epilogue 1
+    conv("c1")
+    c("---- epilogue 1: relu(acc + b1) -> 16 bits -> over the boards in LDS")
+    bias_loads(0)
+    e("s_barrier")                                   # every wave has finished reading the block's input from LDS
+    A.wait(vm_tag=("bias", MT - 1))
+    k = 0
+    for nt in range(NT):
+        for mt in range(MT):
+            t = nt * MT + mt
+            tmp = V_T + 12 * (k % 3)
+            k += 1
+            src, is_v = tile_src(t, tmp)
+            e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 4, 2), vr(src, 2), vr(V_BIAS + 4 * mt, 2)))
+            e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 6, 2), vr(src + 2, 2), vr(V_BIAS + 4 * mt + 2, 2)))
+            if is_v:
+                for i in range(4):
+                    e("v_mov_b32_e32 %s, 0" % vr(src + i))
+            for i in range(4):
+                e("v_max_f32_e32 %s, 0, %s" % (vr(tmp + 4 + i), vr(tmp + 4 + i)))
+            e("%s %s, %s, %s" % (cvt, vr(tmp + 8), vr(tmp + 4), vr(tmp + 5)))
+            e("%s %s, %s, %s" % (cvt, vr(tmp + 9), vr(tmp + 6), vr(tmp + 7)))
+            if len(A.lg_q) >= 3:
+                A.wait(lg_tag=A.lg_q[-3])            # (the temporaries of three tiles ago are free again)
+            A.lg("ds_write_b64 %s, %s offset:%d" % (vr(V_LDSW + nt // 7), vr(tmp + 8, 2), (nt % 7) * 16 * PS + mt * 32), ("w1", t))
+    A.drain()
+    e("s_barrier")                                   # the intermediate boards are complete
+
+    # =============================================================== conv2 + epilogue 2
+    conv("c2")
+    c("---- epilogue 2: relu(acc + b2 + skip) -> 16 bits -> Y (the next block's skip operand) and LDS (its input)")
+    bias_loads(1024)
+    e("s_barrier")                                   # every wave has finished reading the intermediate boards
+
+    def skip_loads(nt):
+        slot, pt = divmod(nt, 9)
+        go = V_GO + nt % 4
+        e("v_add_u32_e32 %s, 0x%x, %s" % (vr(go), pt * 8192, vr(V_GOFF)))
+        for mt in range(MT):
+            A.vm("global_load_dwordx2 %s, %s, %s offset:%d" % (vr(V_SK + (nt % 4) * 8 + mt * 2, 2), vr(go),
+                                                               sr(S_SKIP1 if slot else S_SKIP0, 2), mt * 32), ("skip", nt, mt))
+
+    for nt in range(3):
+        skip_loads(nt)
+    k = 0
+    for nt in range(NT):
+        if nt + 3 < NT:
+            skip_loads(nt + 3)
+        slot = nt // 9
+        go = V_GO + nt % 4
+        for mt in range(MT):
+            t = nt * MT + mt
+            tmp = V_T + 12 * (k % 3)
+            k += 1
+            if nt == 0 and mt == 0:
+                A.wait(vm_tag=("bias", MT - 1))
+            src, is_v = tile_src(t, tmp)
+            e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 4, 2), vr(src, 2), vr(V_BIAS + 4 * mt, 2)))
+            e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 6, 2), vr(src + 2, 2), vr(V_BIAS + 4 * mt + 2, 2)))
+            if is_v:
+                for i in range(4):
+                    e("v_mov_b32_e32 %s, 0" % vr(src + i))
+            A.wait(vm_tag=("skip", nt, mt))
+            sk = V_SK + (nt % 4) * 8 + mt * 2
+            if dt == "bf16":
+                e("v_lshlrev_b32_e32 %s, 16, %s" % (vr(tmp + 0), vr(sk)))
+                e("v_and_b32_e32 %s, 0xffff0000, %s" % (vr(tmp + 1), vr(sk)))
+                e("v_lshlrev_b32_e32 %s, 16, %s" % (vr(tmp + 2), vr(sk + 1)))
+                e("v_and_b32_e32 %s, 0xffff0000, %s" % (vr(tmp + 3), vr(sk + 1)))
+            else:
+                e("v_cvt_f32_f16_e32 %s, %s" % (vr(tmp + 0), vr(sk)))
+                e("v_cvt_f32_f16_sdwa %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" % (vr(tmp + 1), vr(sk)))
+                e("v_cvt_f32_f16_e32 %s, %s" % (vr(tmp + 2), vr(sk + 1)))
+                e("v_cvt_f32_f16_sdwa %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" % (vr(tmp + 3), vr(sk + 1)))
+            e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 4, 2), vr(tmp + 4, 2), vr(tmp + 0, 2)))
+            e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 6, 2), vr(tmp + 6, 2), vr(tmp + 2, 2)))
+            for i in range(4):
+                e("v_max_f32_e32 %s, 0, %s" % (vr(tmp + 4 + i), vr(tmp + 4 + i)))
+            e("%s %s, %s, %s" % (cvt, vr(tmp + 8), vr(tmp + 4), vr(tmp + 5)))
+            e("%s %s, %s, %s" % (cvt, vr(tmp + 9), vr(tmp + 6), vr(tmp + 7)))
+            if len(A.lg_q) >= 3:
+                A.wait(lg_tag=A.lg_q[-3])
+            A.vm("global_store_dwordx2 %s, %s, %s offset:%d" % (vr(go), vr(tmp + 8, 2), sr(S_Y1 if slot else S_Y0, 2), mt * 32),
+                 ("st", t))
+            A.lg("ds_write_b64 %s, %s offset:%d" % (vr(V_LDSW + nt // 7), vr(tmp + 8, 2), (nt % 7) * 16 * PS + mt * 32), ("w2", t))
+    A.drain()
+    e("s_barrier")                                   # the next block's input is complete
+    c("next block: its skip operand is what was just stored")
+    e("s_mov_b64 %s, %s" % (sr(S_SKIP0, 2), sr(S_Y0, 2)))
+    e("s_mov_b64 %s, %s" % (sr(S_SKIP1, 2), sr(S_Y1, 2)))
+    e("s_add_u32 %s, %s, 0x800" % (sr(S_BP), sr(S_BP)))
+    e("s_addc_u32 %s, %s, 0" % (sr(S_BP + 1), sr(S_BP + 1)))
+    e("s_sub_u32 %s, %s, 1" % (sr(S_BLK), sr(S_BLK)))
+    e("s_cmp_lg_u32 %s, 0" % sr(S_BLK))
+    e("s_cbranch_scc1 .L%s_block" % name)
+    A.label(".L%s_end" % name)
+    e("s_endpgm")
+    return A.lines
+
+
+def kernel_text(name, dt, debug=0):
+    body = gen_kernel(name, dt, debug)
+    out = ["\t.text", "\t.globl\t%s" % name, "\t.p2align\t8", "\t.type\t%s,@function" % name, "%s:" % name]
+    out += body
+    out += [".L%s_fend:" % name, "\t.size\t%s, .L%s_fend-%s" % (name, name, name), ""]
+    out += ["\t.section\t.rodata,\"a\",@progbits", "\t.p2align\t6, 0x0", "\t.amdhsa_kernel %s" % name,
+            "\t\t.amdhsa_group_segment_fixed_size %d" % LDS_BYTES,
+            "\t\t.amdhsa_private_segment_fixed_size 0",
+            "\t\t.amdhsa_kernarg_size 56",
+            "\t\t.amdhsa_user_sgpr_count 2",
+            "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1",
+            "\t\t.amdhsa_system_sgpr_workgroup_id_x 1",
+            "\t\t.amdhsa_system_sgpr_workgroup_id_y 0",
+            "\t\t.amdhsa_system_sgpr_workgroup_id_z 0",
+            "\t\t.amdhsa_system_vgpr_workitem_id 0",
+            "\t\t.amdhsa_next_free_vgpr %d" % (NEXT_VGPR + 256),
+            "\t\t.amdhsa_next_free_sgpr %d" % NEXT_SGPR,
+            "\t\t.amdhsa_accum_offset %d" % NEXT_VGPR,
+            "\t\t.amdhsa_reserve_vcc 1",
+            "\t\t.amdhsa_float_round_mode_32 0",
+            "\t\t.amdhsa_float_round_mode_16_64 0",
+            "\t\t.amdhsa_float_denorm_mode_32 3",
+            "\t\t.amdhsa_float_denorm_mode_16_64 3",
+            "\t\t.amdhsa_dx10_clamp 1",
+            "\t\t.amdhsa_ieee_mode 1",
+            "\t.end_amdhsa_kernel", ""]
+    return out
+
+
+def metadata(names):
+    out = ["\t.amdgpu_metadata", "---", "amdhsa.kernels:"]
+    for name in names:
+        out += ["  - .agpr_count:     256", "    .args:"]
+        for i in range(6):
+            out += ["      - .address_space:  global", "        .offset:         %d" % (8 * i), "        .size:           8",
+                    "        .value_kind:     global_buffer"]
+        for off in (48, 52):
+            out += ["      - .offset:         %d" % off, "        .size:           4", "        .value_kind:     by_value"]
+        out += ["    .group_segment_fixed_size: %d" % LDS_BYTES, "    .kernarg_segment_align: 8", "    .kernarg_segment_size: 56",
+                "    .max_flat_workgroup_size: 256", "    .name:           %s" % name, "    .private_segment_fixed_size: 0",
+                "    .sgpr_count:     %d" % (NEXT_SGPR + 6), "    .sgpr_spill_count: 0", "    .symbol:         %s.kd" % name,
+                "    .uniform_work_group_size: 1", "    .uses_dynamic_stack: false", "    .vgpr_count:     %d" % (NEXT_VGPR + 256),
+                "    .vgpr_spill_count: 0", "    .wavefront_size: 64"]
+    out += ["amdhsa.target:   amdgcn-amd-amdhsa--gfx950", "amdhsa.version:", "  - 1", "  - 2", "...", "", "\t.end_amdgpu_metadata"]
+    return out
+
+
+def main():
+    path = sys.argv[1]
+    debug = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    out = ["; generated by gen_tower_asm.py -- do not edit", "\t.amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"",
+           "\t.amdhsa_code_object_version 6", ""]
+    names = ["hive_tower72_bf16", "hive_tower72_f16"]
+    for name, dt in zip(names, ("bf16", "f16")):
+        out += kernel_text(name, dt, debug)
+    out += ["\t.section\t.rodata,\"a\",@progbits", "\t.p2align\t8, 0x0", "\t.globl\thive_tap_table", "\t.type\thive_tap_table,@object",
+            "hive_tap_table:"]
+    tab = tap_table()
+    for i in range(0, len(tab), 16):
+        out.append("\t.long\t" + ", ".join(str(v) for v in tab[i:i + 16]))
+    out += ["\t.size\thive_tap_table, %d" % (4 * len(tab)), ""]
+    out += metadata(names)
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -962,6 +962,8 @@ leaf_dedup_kernel(const HiveBoard *__restrict__ boards, const HiveHistory *__res
                   const unsigned long long *__restrict__ keys, int8_t *__restrict__ need, int32_t *__restrict__ rep,
                   unsigned long long *__restrict__ total)
 {
+    // 96 KB of LDS: this library is built for gfx950 only (160 KB per CU; a 64 KB-LDS target could not launch this kernel)
+    static_assert(kDedupSlots * (sizeof(unsigned long long) + sizeof(int)) + 64 <= 160 * 1024, "leaf_dedup_kernel: table exceeds gfx950's LDS");
     __shared__ unsigned long long tkey[kDedupSlots];
     __shared__ int tmin[kDedupSlots];
     __shared__ int dropped;

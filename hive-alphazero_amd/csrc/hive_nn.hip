@@ -329,8 +329,17 @@ resblock_kernel(const typename E::T *__restrict__ X, const typename E::T *__rest
     const int lr = lane & 15, lg = lane >> 4;
     const long long b = blockIdx.x;
     {
+        // all 18 sixteen-byte loads of a thread are in flight together (as a loop the compiler waited for each one before
+        // issuing the next: 18 dependent L2 / HBM round trips per workgroup before its first MFMA)
         const uint4 *src = reinterpret_cast<const uint4 *>(X + b * 144 * 256);
-        for (int i = tid; i < 144 * 32; i += NT) *reinterpret_cast<uint4 *>(lds + (i >> 5) * PS + (i & 31) * 16) = src[i];
+        uint4 stage[144 * 32 / NT];
+#pragma unroll
+        for (int j = 0; j < 144 * 32 / NT; ++j) stage[j] = src[tid + j * NT];
+#pragma unroll
+        for (int j = 0; j < 144 * 32 / NT; ++j) {
+            const int i = tid + j * NT;
+            *reinterpret_cast<uint4 *>(lds + (i >> 5) * PS + (i & 31) * 16) = stage[j];
+        }
         for (int i = tid; i < PS / 16; i += NT) *reinterpret_cast<uint4 *>(lds + ZOFF + i * 16) = make_uint4(0u, 0u, 0u, 0u);
     }
     f32x4 acc[MT][9];
@@ -604,7 +613,7 @@ extern "C" int hive_nn_tower(const void *x, const void *w, const float *bias, vo
         return set_error(HIVE_E_ARG, "hive_nn_tower: bad argument (y must not alias x)");
     if (!dtype_ok(dtype)) return set_error(HIVE_E_ARG, "hive_nn_tower: dtype must be HIVE_BF16 or HIVE_F16");
     if (boards_per_group < 0 || boards_per_group > 3)
-        return set_error(HIVE_E_ARG, "hive_nn_tower: boards_per_group must be 0 (choose), 1 or 2");
+        return set_error(HIVE_E_ARG, "hive_nn_tower: boards_per_group must be 0 (choose), 1, 2 or 3 (one wave per SIMD)");
     // two boards per workgroup halve the weight stream but leave one workgroup per CU: worth it once the launch has more
     // boards than the chip has workgroup slots of the one-board form (2 x 256)
     const int mode = boards_per_group ? boards_per_group : (batch > 512 ? 2 : 1);

@@ -91,6 +91,10 @@ class TreeSearch:
         # the opening ask about the same few positions (hive_leaf_dedup_launch; batches of up to 4096 rows)
         self.share_equal_leaves = (self.skip_unread_rows and bool(share_equal_leaves) and n <= 4096
                                    and bool(getattr(evaluator, "accepts_rep", False)))
+        if self.skip_unread_rows and share_equal_leaves and n > 4096 and getattr(evaluator, "accepts_rep", False):
+            import warnings
+            warnings.warn(f"TreeSearch: leaf batches of {n} rows exceed hive_leaf_dedup_launch's 4096-row table; equal leaves "
+                          "are evaluated separately (share_equal_leaves off)")
         self.leaf_rep = torch.arange(n, dtype=torch.int32, device=dev)
         self.leaf_keys = torch.zeros((n,), dtype=torch.int64, device=dev)
 
@@ -228,6 +232,7 @@ class SelfPlay:
         self.search.set_game_ids(torch.clamp(self.game_id, min=0))
         # host copies of every ply still needed by a running game (features, history, policy, records, moved?)
         self._log = []
+        self._pinned_pool = []       # page-locked staging sets waiting to be reused (play_ply / _settle)
         self._start_ply = [0] * games   # ply counter at which the game in each slot started
         self._unlogged = [False] * games   # opening plies of this slot's game were played outside play_ply (stagger)
         self.finished_games = []
@@ -349,6 +354,22 @@ class SelfPlay:
             e["csr"] = _csr(e["policy"])
         return e["csr"]
 
+    def _settle(self, e):
+        """A logged ply whose device-to-host copy has completed leaves its page-locked staging buffers: the packed route
+        keeps the sparse policies (the dense 1584-wide rows, 6.5 MB per ply at 1024 games, are dropped) and pageable copies of
+        the small arrays; the row-wise route keeps pageable copies of everything.  The staging set goes back to the pool."""
+        import numpy as np
+        pinned = e.pop("_pinned", None)
+        if pinned is None:
+            return
+        if self.packed_records:
+            self._entry_csr(e)
+            e.pop("policy", None)
+        for k in ("feat", "policy", "boards", "hist", "moved"):
+            if k in e:
+                e[k] = np.array(e[k])
+        self._pinned_pool.append(pinned)
+
     def _pack_from_log(self, keep):
         """The games in `keep` as one packed batch (records.pack_games' arrays; rows grouped by game, plies ascending) --
         the same rows ply_record would cut out one by one, gathered per logged ply with array operations."""
@@ -416,7 +437,14 @@ class SelfPlay:
         persp = 0 if turn % 2 == 1 else 1
         hl = int(entry["boards"][g, 35])
         hlen = (hl & 15) if persp == 0 else (hl >> 4)
-        return (entry["feat"][g].copy(), entry["hist"][g, persp].copy(), hlen, turn, entry["policy"][g].copy(), persp)
+        if "policy" in entry:
+            policy = entry["policy"][g].copy()
+        else:                                    # a settled ply of the packed route keeps the sparse form only
+            import numpy as np
+            ptr, idx, val = entry["csr"]
+            policy = np.zeros(1584, dtype=np.float32)
+            policy[idx[ptr[g]:ptr[g + 1]]] = val[ptr[g]:ptr[g + 1]]
+        return (entry["feat"][g].copy(), entry["hist"][g, persp].copy(), hlen, turn, policy, persp)
 
     def last_ply_record(self, g):
         self._log_ready()
@@ -458,7 +486,10 @@ class SelfPlay:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(self.device))
             prev_copy = self._copy_done
-            host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in src.items()}
+            # page-locked staging buffers are recycled: a ply's arrays move to pageable memory one ply later (_settle), so
+            # two or three sets exist per engine instead of one per ply of the longest running game (8-32 MB each)
+            host = self._pinned_pool.pop() if self._pinned_pool else \
+                {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in src.items()}
             with torch.cuda.stream(self._copy_stream):
                 self._copy_stream.wait_event(ready)
                 for k, v in src.items():
@@ -478,11 +509,11 @@ class SelfPlay:
             oldest = min(self._start_ply)
             while self._log and self._log[0]["ply"] < oldest:
                 self._log.pop(0)
-            if self.packed_records and len(self._log) >= 2 and prev_copy is not None:
+            if len(self._log) >= 2 and prev_copy is not None:
                 # the previous ply's copy was issued a whole search ago: its sparse policies are built now, while the GPU
                 # runs this ply's search (the host has nothing else to do), not when a thousand games end at once
                 prev_copy.synchronize()
-                self._entry_csr(self._log[-2])
+                self._settle(self._log[-2])
         if forced is not None:
             forced = torch.as_tensor(forced, dtype=torch.int32, device=self.device)
             action = torch.where((forced >= -1) & (action != -2), forced, action)

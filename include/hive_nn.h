@@ -63,7 +63,11 @@ int hive_nn_copy_rows(void *y, const int32_t *rep, int batch, long long row_byte
  * A workgroup keeps its board(s) in LDS across all blocks; per block only the skip operand is re-read from, and the
  * block's output written to, global memory (y holds every block's output in turn; at return, the tower's).
  * boards_per_group: 1 = one board per workgroup (two workgroups per CU); 2 = two boards per workgroup (one per CU)
- * sharing every weight fragment fetched from L2 (half the weight stream); 0 = choose by batch size.
+ * whose wave pairs fetch the same weight fragments; 3 = one board per workgroup at ONE wave per SIMD (512 registers:
+ * eight LDS fragment reads in flight, weights two k-steps ahead); 0 = choose by batch size (1 or 2).
+ * The fp16 epilogues round to fp16 without saturating: activations beyond 65504 become inf.  fp16 is validated on the
+ * reference's initialisation and on peaked-head weights (tests/golden/net_wide.npz) and guarded for any other checkpoint
+ * by InferenceNet.range_probe (alpha_net.py), which refuses fp16 within 8x of that limit; bf16 has fp32's range.
  * Results are bit-identical to nblocks calls of hive_nn_resblock_dt. */
 int hive_nn_tower(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
                   int boards_per_group, void *stream);
