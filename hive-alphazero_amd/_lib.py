@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "hive_search_leaf_need",
     # include/hive_nn.h
     "hive_nn_conv3x3", "hive_nn_resblock", "hive_nn_conv3x3_dt", "hive_nn_resblock_dt", "hive_nn_tower",
-    "hive_nn_conv3x3_sel", "hive_nn_resblock_sel", "hive_nn_copy_rows",
+    "hive_nn_conv3x3_sel", "hive_nn_resblock_sel", "hive_nn_copy_rows", "hive_nn_tower72", "hive_nn_compact_rows",
     "hive_nn_bn_workspace_floats", "hive_nn_bn_act_fwd", "hive_nn_bn_act_bwd",
     "hive_nn_pack_conv3x3_weights", "hive_nn_conv3x3_wgrad", "hive_nn_wgrad_workspace_floats",
 ]
@@ -54,7 +54,7 @@ class HiveError(RuntimeError):
 
 def build(force=False):
     """Compile csrc/*.hip for gfx950 into libhive_hip.so (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".hpp", "gen_tower_asm.py"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "hive_abi.h"))
     stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if force or stale:
@@ -127,6 +127,8 @@ def load():
     L.hive_nn_resblock_sel.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     L.hive_search_leaf_need.argtypes = [vp, i32, vp, vp, vp, vp]
     L.hive_nn_copy_rows.argtypes = [vp, vp, i32, ctypes.c_longlong, vp]
+    L.hive_nn_tower72.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    L.hive_nn_compact_rows.argtypes = [vp, i32, vp, vp, vp]
     L.hive_leaf_dedup_launch.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
     f32, i64 = ctypes.c_float, ctypes.c_longlong
     L.hive_nn_bn_workspace_floats.restype = i32

@@ -35,14 +35,14 @@ KSTEP_BYTES = 16 * 1024       # one k-step of packed weights (16 fragments of 1 
 V_TID = 0
 V_WLANE = 1                   # wave * 4096 + lane * 16: this lane's byte offset inside a k-step's fragments
 V_TAB = 2                     # lane * 4
-V_BOFF = 3                    # 18: LDS byte offset of this lane's fragment row of pixel tile nt under the current tap
+V_BOFF = 4                    # 18 (register tuples must start on even registers): LDS byte offset of this lane's fragment row of pixel tile nt under the current tap
 V_BOFFN = V_BOFF + NT         # 18: ... under the next tap
 V_A = V_BOFFN + NT            # 64: weight ring [ARING][MT][4]
 V_B = V_A + ARING * MT * 4    # 24: pixel-fragment ring [BRING][4]
 V_ACC = V_B + BRING * 4       # 32: accumulator tiles 64..71
 V_BIAS = V_ACC + 32           # 16: bias[mt][4]
-V_T = V_BIAS + 16             # 36: epilogue temporaries (3 sets of 12)
-V_SK = V_T + 36               # 32: skip operands in flight (4 batches x 4 tiles x 2)
+V_T = V_BIAS + 16             # 30: epilogue temporaries (3 sets of 10)
+V_SK = V_T + 30               # 32: skip operands in flight (4 batches x 4 tiles x 2)
 V_GO = V_SK + 32              # 4: global pixel offsets of the batches in flight
 V_LDSW = V_GO + 4             # 3: epilogue LDS write bases
 V_GOFF = V_LDSW + 3           # 1: lr * 512 + lg * 8 + wave * 128
@@ -72,6 +72,7 @@ S_WAVE = 40
 S_R0, S_R1 = 41, 42
 S_T1, S_T2, S_T3 = 43, 44, 45
 S_SRC = 46                    # pair: staging source
+S_HAS1 = 48                   # pair: exec mask for the second board's global stores (0 when the pair's second entry repeats the first)
 NEXT_SGPR = 56
 
 
@@ -170,7 +171,9 @@ def gen_kernel(name, dt, debug=0):
     e("s_load_dwordx4 %s, %s, 0x20" % (sr(S_IDX, 4), sr(S_KARG, 2)))
     e("s_load_dwordx2 %s, %s, 0x30" % (sr(S_N, 2), sr(S_KARG, 2)))
     e("v_lshrrev_b32_e32 %s, 6, %s" % (vr(V_TMP), vr(V_TID)))
+    e("s_nop 1")                                 # (a VALU-written register is not yet visible to v_readfirstlane)
     e("v_readfirstlane_b32 %s, %s" % (sr(S_WAVE), vr(V_TMP)))
+    e("s_nop 4")
     e("s_waitcnt lgkmcnt(0)")
     c("n = count ? *count : batch")
     e("s_cmp_eq_u64 %s, 0" % sr(S_CNT, 2))
@@ -181,10 +184,11 @@ def gen_kernel(name, dt, debug=0):
     e("s_lshl_b32 %s, %s, 1" % (sr(S_R0), sr(S_WG)))
     e("s_cmp_ge_u32 %s, %s" % (sr(S_R0), sr(S_N)))
     e("s_cbranch_scc1 .L%s_end" % name)
-    c("second entry of the pair; an odd tail repeats the first (both halves then compute and store identical values)")
+    c("second entry of the pair; an odd tail repeats the first board (its copy computes along and stores nothing)")
     e("s_add_u32 %s, %s, 1" % (sr(S_R1), sr(S_R0)))
     e("s_cmp_ge_u32 %s, %s" % (sr(S_R1), sr(S_N)))
     e("s_cselect_b32 %s, %s, %s" % (sr(S_R1), sr(S_R0), sr(S_R1)))
+    e("s_cselect_b64 %s, 0, -1" % sr(S_HAS1, 2))      # exec mask of the second board's stores: nothing if it is a repeat
     e("s_cmp_eq_u64 %s, 0" % sr(S_IDX, 2))
     e("s_cbranch_scc1 .L%s_rows" % name)
     e("s_lshl_b32 %s, %s, 2" % (sr(S_T1), sr(S_R0)))
@@ -268,13 +272,20 @@ def gen_kernel(name, dt, debug=0):
         A.lg("ds_write_b128 %s, %s offset:%d" % (addr, vr(V_STAGE + 4 * k, 4), lo), ("stw", k))
         if len(A.lg_q) > 12:
             A.wait(lg_tag=A.lg_q[-8])
+    e("s_nop 1")                                 # (a 16-byte LDS write's data registers must not be rewritten at once)
     for i in range(32):                          # (after the staging data has left these registers)
         e("v_mov_b32_e32 %s, 0" % vr(V_ACC + i))
 
-    if debug == 1:
-        c("DEBUG 1: copy the LDS image back out (identity) and stop")
+    def dump_lds_and_stop():
         A.drain()
         e("s_barrier")
+        ST_ADDR, ST_G = V_TMP + 2, V_TMP + 3         # (recomputed: the prologue's copies lived in the boff registers)
+        e("v_lshrrev_b32_e32 %s, 5, %s" % (vr(ST_ADDR), vr(V_TID)))
+        e("v_mul_u32_u24_e32 %s, 0x%x, %s" % (vr(ST_ADDR), PS, vr(ST_ADDR)))
+        e("v_and_b32_e32 %s, 31, %s" % (vr(V_TMP), vr(V_TID)))
+        e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(V_TMP), vr(V_TMP)))
+        e("v_add_u32_e32 %s, %s, %s" % (vr(ST_ADDR), vr(ST_ADDR), vr(V_TMP)))
+        e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(ST_G), vr(V_TID)))
         for s_, base in ((0, S_Y0), (1, S_Y1)):
             e("s_mov_b64 %s, %s" % (sr(S_SRC, 2), sr(base, 2)))
             for j in range(18):
@@ -290,6 +301,25 @@ def gen_kernel(name, dt, debug=0):
                 e("s_nop 1")
                 e("s_add_u32 %s, %s, 0x1000" % (sr(S_SRC), sr(S_SRC)))
                 e("s_addc_u32 %s, %s, 0" % (sr(S_SRC + 1), sr(S_SRC + 1)))
+        e("s_waitcnt vmcnt(0)")
+        e("s_endpgm")
+        A.label(".L%s_end" % name)
+        e("s_endpgm")
+        return A.lines
+
+    if debug == 1:
+        c("DEBUG 1: copy the LDS image back out (identity) and stop")
+        return dump_lds_and_stop()
+    if debug == 4:
+        c("DEBUG 4: every thread stores its lane constants (16 dwords at Y + tid * 64) and stops")
+        A.drain()
+        regs = [V_TID, V_WLANE, V_TAB, V_LDSW, V_LDSW + 1, V_LDSW + 2, V_GOFF, V_BIASOFF]
+        e("v_lshlrev_b32_e32 %s, 6, %s" % (vr(V_TMP), vr(V_TID)))
+        for i, r in enumerate(regs):
+            e("global_store_dword %s, %s, %s offset:%d" % (vr(V_TMP), vr(r), sr(S_Y, 2), 4 * i))
+        for i, sreg in enumerate((S_WAVE, S_WG, S_N, S_NBLK, S_R0, S_R1, S_Y0, S_Y1)):
+            e("v_mov_b32_e32 %s, %s" % (vr(V_TMP + 1), sr(sreg)))
+            e("global_store_dword %s, %s, %s offset:%d" % (vr(V_TMP), vr(V_TMP + 1), sr(S_Y, 2), 32 + 4 * i))
         e("s_waitcnt vmcnt(0)")
         e("s_endpgm")
         A.label(".L%s_end" % name)
@@ -395,6 +425,9 @@ def gen_kernel(name, dt, debug=0):
                  ("bias", mt))
 
     A.label(".L%s_block" % name)
+    if debug == 2:
+        c("DEBUG 2: no convolutions -- epilogue 2 on zero accumulators: y = relu(b2 + x)")
+        e("s_branch .L%s_epi2" % name)
     # =============================================================== conv1 + epilogue 1
     conv("c1")
     c("---- epilogue 1: relu(acc + b1) -> 16 bits -> over the boards in LDS")
@@ -405,7 +438,7 @@ def gen_kernel(name, dt, debug=0):
     for nt in range(NT):
         for mt in range(MT):
             t = nt * MT + mt
-            tmp = V_T + 12 * (k % 3)
+            tmp = V_T + 10 * (k % 3)
             k += 1
             src, is_v = tile_src(t, tmp)
             e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 4, 2), vr(src, 2), vr(V_BIAS + 4 * mt, 2)))
@@ -422,9 +455,13 @@ def gen_kernel(name, dt, debug=0):
             A.lg("ds_write_b64 %s, %s offset:%d" % (vr(V_LDSW + nt // 7), vr(tmp + 8, 2), (nt % 7) * 16 * PS + mt * 32), ("w1", t))
     A.drain()
     e("s_barrier")                                   # the intermediate boards are complete
+    if debug == 3:
+        c("DEBUG 3: the intermediate boards (relu(conv1 + b1)) back out, stop")
+        return dump_lds_and_stop()
 
     # =============================================================== conv2 + epilogue 2
     conv("c2")
+    A.label(".L%s_epi2" % name)
     c("---- epilogue 2: relu(acc + b2 + skip) -> 16 bits -> Y (the next block's skip operand) and LDS (its input)")
     bias_loads(1024)
     e("s_barrier")                                   # every wave has finished reading the intermediate boards
@@ -447,7 +484,7 @@ def gen_kernel(name, dt, debug=0):
         go = V_GO + nt % 4
         for mt in range(MT):
             t = nt * MT + mt
-            tmp = V_T + 12 * (k % 3)
+            tmp = V_T + 10 * (k % 3)
             k += 1
             if nt == 0 and mt == 0:
                 A.wait(vm_tag=("bias", MT - 1))
@@ -477,8 +514,12 @@ def gen_kernel(name, dt, debug=0):
             e("%s %s, %s, %s" % (cvt, vr(tmp + 9), vr(tmp + 6), vr(tmp + 7)))
             if len(A.lg_q) >= 3:
                 A.wait(lg_tag=A.lg_q[-3])
+            if slot:
+                e("s_mov_b64 exec, %s" % sr(S_HAS1, 2))
             A.vm("global_store_dwordx2 %s, %s, %s offset:%d" % (vr(go), vr(tmp + 8, 2), sr(S_Y1 if slot else S_Y0, 2), mt * 32),
                  ("st", t))
+            if slot:
+                e("s_mov_b64 exec, -1")
             A.lg("ds_write_b64 %s, %s offset:%d" % (vr(V_LDSW + nt // 7), vr(tmp + 8, 2), (nt % 7) * 16 * PS + mt * 32), ("w2", t))
     A.drain()
     e("s_barrier")                                   # the next block's input is complete
@@ -550,7 +591,7 @@ def main():
     names = ["hive_tower72_bf16", "hive_tower72_f16"]
     for name, dt in zip(names, ("bf16", "f16")):
         out += kernel_text(name, dt, debug)
-    out += ["\t.section\t.rodata,\"a\",@progbits", "\t.p2align\t8, 0x0", "\t.globl\thive_tap_table", "\t.type\thive_tap_table,@object",
+    out += ["\t.section\t.rodata,\"a\",@progbits", "\t.p2align\t8, 0x0", "\t.type\thive_tap_table,@object",
             "hive_tap_table:"]
     tab = tap_table()
     for i in range(0, len(tab), 16):

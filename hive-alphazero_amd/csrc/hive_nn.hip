@@ -21,6 +21,8 @@
 //                  fragment traffic per MFMA.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <mutex>
 #include <string>
 
 #include "../../include/hive_abi.h"
@@ -604,6 +606,120 @@ static void launch_tower(const void *x, const void *w, const float *bias, void *
     if (mode == 1) hipLaunchKernelGGL((tower_kernel<E, 1, 1, 2, HIVE_CONV_BDEPTH, 1>), dim3((unsigned)batch), dim3(256), 0, s, X, Wt, bias, Y, batch, nblocks);
     else if (mode == 2) hipLaunchKernelGGL((tower_kernel<E, 2, 2, 2, HIVE_CONV_BDEPTH, 1>), dim3((unsigned)((batch + 1) / 2)), dim3(512), 0, s, X, Wt, bias, Y, batch, nblocks);
     else hipLaunchKernelGGL((tower_kernel<E, 1, 1, 1, HIVE_TOWER_BDEPTH, HIVE_TOWER_ADIST>), dim3((unsigned)batch), dim3(256), 0, s, X, Wt, bias, Y, batch, nblocks);
+}
+
+// ---------------------------------------------------------------------------------------------
+// hive_tower72_{bf16,f16}: the tower with a 72-tile wave, written in assembly (gen_tower_asm.py -> tower72_gfx950.hsaco,
+// embedded here): two boards per workgroup, one wave per SIMD, 288 accumulator registers per lane.
+#if !defined(__HIP_DEVICE_COMPILE__)
+asm(".section .rodata\n"
+    ".p2align 12\n"
+    ".global hive_tower72_hsaco\n"
+    "hive_tower72_hsaco:\n"
+    ".incbin \"tower72_gfx950.hsaco\"\n"
+    ".global hive_tower72_hsaco_end\n"
+    "hive_tower72_hsaco_end:\n"
+    ".byte 0\n"
+    ".text\n");
+#endif
+extern "C" const unsigned char hive_tower72_hsaco[];
+
+namespace {
+struct Tower72Args {
+    const void *x, *w;
+    const float *bias;
+    void *y;
+    const int32_t *rows, *nrows;
+    int32_t batch, nblocks;
+};
+static_assert(sizeof(Tower72Args) == 56, "kernarg layout of hive_tower72_* (gen_tower_asm.py)");
+
+struct Tower72Module {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn[2] = {nullptr, nullptr};
+};
+
+// one module per device (a code object is loaded into the current device's context)
+int tower72_function(int dtype, hipFunction_t *out)
+{
+    static std::mutex mu;
+    static Tower72Module mods[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hive::set_error(HIVE_E_DEVICE, "hive_nn_tower72: no current device");
+    std::lock_guard<std::mutex> lock(mu);
+    Tower72Module &m = mods[dev];
+    if (!m.mod) {
+        // (HIVE_TOWER72_HSACO: a development switch -- load another build of the generated kernel, e.g. a debug or A/B variant)
+        const char *alt = getenv("HIVE_TOWER72_HSACO");
+        hipError_t e = alt && *alt ? hipModuleLoad(&m.mod, alt) : hipModuleLoadData(&m.mod, hive_tower72_hsaco);
+        if (e == hipSuccess) e = hipModuleGetFunction(&m.fn[0], m.mod, "hive_tower72_bf16");
+        if (e == hipSuccess) e = hipModuleGetFunction(&m.fn[1], m.mod, "hive_tower72_f16");
+        if (e != hipSuccess) {
+            m.mod = nullptr;
+            return hive::set_error(HIVE_E_DEVICE, std::string("hive_nn_tower72: loading the code object: ") + hipGetErrorString(e));
+        }
+    }
+    *out = m.fn[dtype == HIVE_BF16 ? 0 : 1];
+    return HIVE_OK;
+}
+
+// rows[k] = index of the k-th board flagged in `need` (ascending), *nrows = how many: what hive_tower72_* iterates over
+__global__ void __launch_bounds__(1024)
+compact_rows_kernel(const int8_t *__restrict__ need, int batch, int32_t *__restrict__ rows, int32_t *__restrict__ nrows)
+{
+    __shared__ int wave_count[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int lo = 0; lo < batch; lo += 1024) {
+        const int i = lo + tid;
+        const bool on = i < batch && need[i] != 0;
+        const unsigned long long bal = __ballot(on);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_count[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_count[w];
+        if (on) rows[off + before] = i;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wave_count[w];
+            base += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *nrows = base;
+}
+}  // namespace
+
+extern "C" int hive_nn_compact_rows(const int8_t *need, int batch, int32_t *rows, int32_t *nrows, void *stream)
+{
+    if (!need || !rows || !nrows || batch <= 0) return set_error(HIVE_E_ARG, "hive_nn_compact_rows: bad argument");
+    hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, need, batch, rows, nrows);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(HIVE_E_DEVICE, std::string("hive_nn_compact_rows: ") + hipGetErrorString(e));
+    return HIVE_OK;
+}
+
+extern "C" int hive_nn_tower72(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
+                               const int32_t *rows, const int32_t *nrows, void *stream)
+{
+    if (!x || !w || !bias || !y || batch <= 0 || nblocks <= 0 || x == y)
+        return set_error(HIVE_E_ARG, "hive_nn_tower72: bad argument (y must not alias x)");
+    if (!dtype_ok(dtype)) return set_error(HIVE_E_ARG, "hive_nn_tower72: dtype must be HIVE_BF16 or HIVE_F16");
+    if ((rows == nullptr) != (nrows == nullptr))
+        return set_error(HIVE_E_ARG, "hive_nn_tower72: rows and nrows come together (hive_nn_compact_rows) or not at all");
+    hipFunction_t fn = nullptr;
+    int rc = tower72_function(dtype, &fn);
+    if (rc != HIVE_OK) return rc;
+    Tower72Args args{x, w, bias, y, rows, nrows, batch, nblocks};
+    size_t size = sizeof(args);
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    hipError_t e = hipModuleLaunchKernel(fn, (unsigned)((batch + 1) / 2), 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, config);
+    if (e != hipSuccess) return set_error(HIVE_E_DEVICE, std::string("hive_nn_tower72: ") + hipGetErrorString(e));
+    return HIVE_OK;
 }
 
 extern "C" int hive_nn_tower(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,

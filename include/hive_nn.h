@@ -72,6 +72,19 @@ int hive_nn_copy_rows(void *y, const int32_t *rep, int batch, long long row_byte
 int hive_nn_tower(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
                   int boards_per_group, void *stream);
 
+/* The same tower with a 72-tile wave (hand-written gfx950 assembly, csrc/gen_tower_asm.py): TWO boards per 4-wave
+ * workgroup, one wave per SIMD, every wave accumulating 64 output channels x both boards' 288 pixels in 288 accumulator
+ * registers, so that every weight fragment fetched from L2 feeds two boards.  Same arguments, layouts and bits as
+ * hive_nn_tower (bit-identical to nblocks calls of hive_nn_resblock_dt).
+ * rows / nrows (both NULL, or both device pointers): the boards to evaluate -- rows[0 .. *nrows-1] ascending board indices
+ * (hive_nn_compact_rows of the leaf batch's `need` flags); boards not listed keep whatever y held.  The launch covers
+ * ceil(batch / 2) workgroups; those beyond *nrows return at once. */
+int hive_nn_tower72(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
+                    const int32_t *rows, const int32_t *nrows, void *stream);
+
+/* need int8[batch] (1 = evaluate) -> rows int32[batch] (indices of the flagged boards, ascending), *nrows = their number. */
+int hive_nn_compact_rows(const int8_t *need, int batch, int32_t *rows, int32_t *nrows, void *stream);
+
 /* Training-mode BatchNorm2d + optional skip connection + optional ReLU of the 256-channel tower, forward and
  * backward (alpha_net.py:25-54 as executed by the training step alpha_net.py:117-162), channels-last bf16:
  *   forward : y = act( (x - mean_c) / sqrt(var_c + eps) * gamma_c + beta_c (+ residual) ), batch statistics over all
