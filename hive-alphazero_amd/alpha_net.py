@@ -399,12 +399,13 @@ class InferenceNet:
     conv = "hip" (default for bf16 / fp16 on a GPU): the 39 3x3 convolutions run in the hand-written MFMA kernels
     (hive_nn_conv3x3_dt for the stem, hive_nn_resblock_dt per residual block) with bias / skip / ReLU fused;
     conv = "torch": MIOpen through F.conv2d (the fp32 path, the reference's own precision, api_hive.py:62-69).
-    tower: 0 = one hive_nn_resblock_dt launch per residual block (default: measured fastest, profiles/r03_net_tower.md);
-    1 / 2 / 3 = the whole tower in one hive_nn_tower launch (its boards_per_group modes; same bits)."""
+    tower: "auto" (default) = the 72-tile assembly tower hive_nn_tower72 for batches that fill its rounds, else 0;
+    0 = one hive_nn_resblock_dt launch per residual block; 72 = hive_nn_tower72 always; 1 / 2 / 3 = the whole tower in one
+    hive_nn_tower launch (its boards_per_group modes).  All forms produce the same bits."""
 
     FP16_HEADROOM = 8.0                  # fp16 is chosen only while every probed magnitude stays below 65504 / 8
 
-    def __init__(self, net, dtype=None, device=None, use_graph=True, conv=None, tune_gemms=True, tower=0):
+    def __init__(self, net, dtype=None, device=None, use_graph=True, conv=None, tune_gemms=True, tower="auto"):
         """dtype None = choose on measurement (api_hive.py:56-69 evaluates in fp32; fp16 reproduces its search in 100 % of
         the test positions, bf16 in 97.7 %, tests/test_net.py): fp16 on a GPU when `range_probe` shows the BatchNorm-folded
         weights and every layer's activations on a batch of playout positions at least FP16_HEADROOM below the fp16
@@ -420,7 +421,7 @@ class InferenceNet:
             conv = "hip" if hip_ok else "torch"
         if conv == "hip" and not hip_ok:
             raise ValueError("the HIP convolution path is bf16 or fp16 on a GPU")
-        self.conv, self.tower = conv, int(tower)
+        self.conv, self.tower = conv, (tower if tower == "auto" else int(tower))
         # large leaf batches: let PyTorch's TunableOp pick the hipBLASLt solutions of the head GEMMs once, before the graph
         # is captured (the default heuristic runs the 1024 x 18432 x 1584 policy FC at 178 us, the tuned pick at 92 us)
         self.tune_gemms = tune_gemms and dev.type == "cuda"
@@ -566,6 +567,19 @@ class InferenceNet:
                                           ctypes.c_void_p(need.data_ptr()) if need is not None else None, st))
         return out
 
+    def _tower_form(self, B):
+        """The launch form of the 19 residual blocks for a batch of B boards: self.tower, with "auto" resolved.
+        The 72-tile tower (72) runs one 2-board workgroup per CU and a whole tower per workgroup, so its time is
+        ceil(B / 512) rounds of ~2.0 ms whatever part of the last round is filled (1024 boards: 4.00 ms against 4.76 ms for
+        the launch-per-block chain, profiles/r04_net_tower72.md); the chain's time is proportional to B.  auto = the tower
+        when its last round is at least 86 % full."""
+        if self.tower != "auto":
+            return self.tower
+        if not self.fuse_blocks or B < 440:
+            return 0
+        rounds = -(-B // 512)
+        return 72 if B >= 0.86 * rounds * 512 else 0
+
     def _tower_hip(self, x_hwc, need=None, rep=None):
         """need: int8[B] on the device or None -- boards flagged 0 are skipped by every kernel of the tower (their rows of
         the activation buffers keep stale, finite values; the heads compute on them and nobody reads the result).
@@ -585,8 +599,9 @@ class InferenceNet:
     def _tower_hip_rows(self, x_hwc, need=None):
         B = x_hwc.shape[0]
         x_hwc = x_hwc.contiguous()
-        if need is not None and (self.tower or not self.fuse_blocks):
-            need = None                      # only the shipped launch-per-block form takes the selection
+        tower = self._tower_form(B)
+        if need is not None and ((tower and tower != 72) or not self.fuse_blocks):
+            need = None                      # the launch-per-block form and the 72-tile tower take the selection
         # a skipped board's rows must hold finite numbers: eager calls start from zeros; a captured graph owns its buffers
         # for good and _call_locked replays it once with every board selected before the first real call
         alloc = torch.zeros if need is not None and not torch.cuda.is_current_stream_capturing() else torch.empty
@@ -601,11 +616,26 @@ class InferenceNet:
         def needp(lo):
             return ctypes.c_void_p(need.data_ptr() + lo) if need is not None else None
 
-        if self.tower:
+        if tower == 72:
+            # the 72-tile assembly tower (hive_nn_tower72): two boards per workgroup, all 19 blocks in one launch; the
+            # boards to evaluate travel as a compacted row list (hive_nn_compact_rows of the need flags)
+            tw, tb = self.h_tower
+            rows = nrows = None
+            if need is not None:
+                rows = torch.empty((B,), dtype=torch.int32, device=self.device)
+                nrows = torch.empty((1,), dtype=torch.int32, device=self.device)
+                check(self._L.hive_nn_compact_rows(ctypes.c_void_p(need.data_ptr()), B, ctypes.c_void_p(rows.data_ptr()),
+                                                   ctypes.c_void_p(nrows.data_ptr()), st))
+            check(self._L.hive_nn_tower72(ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(tw.data_ptr()),
+                                          ctypes.c_void_p(tb.data_ptr()), ctypes.c_void_p(bufs[1].data_ptr()), B, 19, dt,
+                                          ctypes.c_void_p(rows.data_ptr()) if rows is not None else None,
+                                          ctypes.c_void_p(nrows.data_ptr()) if nrows is not None else None, st))
+            return bufs[1].permute(0, 3, 1, 2)
+        if tower:
             tw, tb = self.h_tower
             check(self._L.hive_nn_tower(ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(tw.data_ptr()),
                                         ctypes.c_void_p(tb.data_ptr()), ctypes.c_void_p(bufs[1].data_ptr()), B, 19, dt,
-                                        self.tower, st))
+                                        tower, st))
             return bufs[1].permute(0, 3, 1, 2)
         if self.fuse_blocks and self.split_streams and B >= 512:
             # Boards are independent: only the 19 blocks of ONE board are ordered.  A single stream makes every block a
@@ -703,7 +733,7 @@ class InferenceNet:
     def accepts_need(self):
         """__call__ honours the row selection of hive_search_leaf_need (mcts.TreeSearch asks): the HIP tower only -- the
         library path evaluates every row, and says so, so that the search's rows-evaluated counter stays true."""
-        return self.conv == "hip" and self.tower == 0 and self.fuse_blocks
+        return self.conv == "hip" and self.tower in (0, 72, "auto") and self.fuse_blocks
 
     accepts_rep = accepts_need   # ... and the representatives of equal rows (hive_leaf_dedup_launch)
 

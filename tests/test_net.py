@@ -685,6 +685,54 @@ def test_reduced_precision_search_agrees_with_fp32_search():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_hip_tower72_matches_resblock_chain(dtype):
+    """hive_nn_tower72 (the 72-tile assembly tower: two boards per workgroup, 288 accumulator registers per lane,
+    csrc/gen_tower_asm.py) against the launch-per-block chain hive_nn_resblock_dt, through the C ABI, bit for bit:
+    one and several blocks, odd batches (the tail workgroup repeats its board and stores it once), more boards than one
+    round of the chip, and with a row list (hive_nn_compact_rows of random need flags: unlisted boards keep their bytes)."""
+    assert torch.cuda.is_available()
+    import ctypes
+    from hive_alphazero_amd import _lib
+    L = _lib.load()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    DT = _lib.BF16 if dtype == torch.bfloat16 else _lib.F16
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    for B, nblk, use_rows in ((2, 1, False), (5, 1, False), (7, 2, False), (64, 3, True), (1, 2, False), (600, 19, True), (1031, 4, False)):
+        x = torch.relu(torch.randn((B, 144, 256), device="cuda", generator=gen)).to(dtype)
+        w = (torch.randn((2 * nblk, 9 * 8 * 16 * 64 * 8), device="cuda", generator=gen) * 0.015).to(dtype)
+        bias = torch.randn((2 * nblk, 256), device="cuda", generator=gen) * 0.1
+        bufs = [x, torch.zeros_like(x), torch.zeros_like(x)]
+        cur = 0
+        for i in range(nblk):
+            nxt = 1 if cur != 1 else 2
+            _lib.check(L.hive_nn_resblock_dt(P(bufs[cur]), P(w[2 * i]), P(bias[2 * i]), P(w[2 * i + 1]), P(bias[2 * i + 1]),
+                                             P(bufs[nxt]), B, DT, st()))
+            cur = nxt
+        want = bufs[cur]
+        y = torch.full_like(x, 7.0)
+        rows = nrows = need = None
+        if use_rows:
+            need = (torch.rand((B,), device="cuda", generator=gen) < 0.9).to(torch.int8)
+            rows = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+            nrows = torch.zeros((1,), dtype=torch.int32, device="cuda")
+            _lib.check(L.hive_nn_compact_rows(P(need), B, P(rows), P(nrows), st()))
+            k = int(nrows.item())
+            assert k == int(need.sum().item()) and torch.equal(rows[:k].long(), torch.nonzero(need).flatten())
+        _lib.check(L.hive_nn_tower72(P(x), P(w), P(bias), P(y), B, nblk, DT, P(rows), P(nrows), st()))
+        torch.cuda.synchronize()
+        if use_rows:
+            sel = need.bool()
+            assert torch.equal(y[sel], want[sel]) and bool((y[~sel] == 7.0).all()), (B, nblk)
+        else:
+            assert torch.equal(y, want), (B, nblk, int((y != want).sum()))
+    # arguments: rows without a count, aliased output
+    assert L.hive_nn_tower72(P(x), P(w), P(bias), P(y), B, nblk, DT, P(y), None, st()) != 0
+    assert L.hive_nn_tower72(P(x), P(w), P(bias), P(x), B, nblk, DT, None, None, st()) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_inference_net_tower_forms_give_the_same_bits(dtype):
     """InferenceNet(tower=1|2|3) (the whole residual tower in one hive_nn_tower launch, three workgroup forms) against the
     default launch-per-block chain: identical policy and value outputs, eagerly and through the captured HIP graph, and
@@ -699,9 +747,9 @@ def test_inference_net_tower_forms_give_the_same_bits(dtype):
     p0, v0 = ref(x)
     # leaf batches >= 512 run as two half-batch chains on two streams: same bits as one chain, eagerly and replayed
     xl = (torch.rand((640, 12, 12, 56), device="cuda") < 0.08).to(dtype)
-    one = InferenceNet(net, dtype=dtype, tune_gemms=False)
+    one = InferenceNet(net, dtype=dtype, tune_gemms=False, tower=0)
     one.split_streams = False
-    two = InferenceNet(net, dtype=dtype, tune_gemms=False)
+    two = InferenceNet(net, dtype=dtype, tune_gemms=False, tower=0)
     assert two.split_streams
     pa, va = one(xl)
     for _ in range(3):
@@ -714,7 +762,15 @@ def test_inference_net_tower_forms_give_the_same_bits(dtype):
         for _ in range(2):
             pb, vb = two(xb)
             assert torch.equal(pa, pb) and torch.equal(va, vb), rows
-    engines = {t: InferenceNet(net, dtype=dtype, tower=t) for t in (1, 2, 3)}
+    # the default ("auto") takes the 72-tile assembly tower for batches that fill its rounds: same bits as the chain
+    auto = InferenceNet(net, dtype=dtype, tune_gemms=False)
+    assert auto._tower_form(1024) == 72 and auto._tower_form(960) == 72 and auto._tower_form(640) == 0 and auto._tower_form(37) == 0
+    xb = (torch.rand((1000, 12, 12, 56), device="cuda") < 0.08).to(dtype)
+    pa, va = one(xb)
+    for _ in range(2):
+        pb, vb = auto(xb)
+        assert torch.equal(pa, pb) and torch.equal(va, vb)
+    engines = {t: InferenceNet(net, dtype=dtype, tower=t) for t in (1, 2, 3, 72)}
     for t, inf in engines.items():
         p, v = inf(x)
         assert torch.equal(p, p0) and torch.equal(v, v0), t
@@ -744,12 +800,12 @@ def test_inference_net_row_selection_keeps_the_selected_rows_bit_identical(dtype
     torch.manual_seed(3)
     net = ChessNet().cuda().eval()
     gen = torch.Generator(device="cuda").manual_seed(5)
-    for B in (37, 640):
+    for B, form in ((37, 0), (640, 0), (45, 72), (1000, 72)):      # (72: the assembly tower takes the rows as a compacted list)
         x = (torch.rand((B, 12, 12, 56), device="cuda", generator=gen) < 0.08).to(dtype)
-        full = InferenceNet(net, dtype=dtype, tune_gemms=False)
+        full = InferenceNet(net, dtype=dtype, tune_gemms=False, tower=0)
         p0, v0 = full(x)
         for use_graph in (False, True):
-            inf = InferenceNet(net, dtype=dtype, tune_gemms=False, use_graph=use_graph)
+            inf = InferenceNet(net, dtype=dtype, tune_gemms=False, use_graph=use_graph, tower=form)
             for frac in (0.9, 0.5, 1.0, 0.0, 0.97):
                 need = (torch.rand((B,), device="cuda", generator=gen) < frac).to(torch.int8)
                 p, v = inf(x, need=need)
@@ -787,7 +843,7 @@ def test_inference_net_equal_rows_take_their_representatives_tower_output():
     torch.manual_seed(4)
     net = ChessNet().cuda().eval()
     gen = torch.Generator(device="cuda").manual_seed(6)
-    for B, use_graph in ((96, False), (1024, True)):
+    for B, use_graph, form in ((96, False, 0), (1024, True, "auto"), (88, False, 72)):
         base = (torch.rand((B // 8, 12, 12, 56), device="cuda", generator=gen) < 0.08).to(torch.bfloat16)
         which = torch.randint(0, B // 8, (B,), device="cuda", generator=gen)
         x = base[which]
@@ -798,9 +854,9 @@ def test_inference_net_equal_rows_take_their_representatives_tower_output():
             rep[i] = first.setdefault(int(w[i]), i)
         need = torch.from_numpy((rep == np.arange(B)).astype(np.int8)).cuda()
         trep = torch.from_numpy(rep).cuda()
-        plain = InferenceNet(net, dtype=torch.bfloat16, use_graph=use_graph)
+        plain = InferenceNet(net, dtype=torch.bfloat16, use_graph=use_graph, tower=0)
         p0, v0 = plain(x)
-        inf = InferenceNet(net, dtype=torch.bfloat16, use_graph=use_graph)
+        inf = InferenceNet(net, dtype=torch.bfloat16, use_graph=use_graph, tower=form)
         for _ in range(2):
             p, v = inf(x, need=need, rep=trep)
             assert torch.equal(p, p0) and torch.equal(v, v0), (B, use_graph)

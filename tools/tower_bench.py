@@ -58,12 +58,32 @@ for dtype in (torch.bfloat16, torch.float16):
             return y[0]
         return run
 
+    def tower72(lib):
+        def run(y):
+            assert lib.hive_nn_tower72(P(x), P(w), P(bias), P(y[0]), B, NBLK, DT[dtype], None, None, st()) == 0, L.hive_last_error()
+            return y[0]
+        return run
+
+    def tower72_chain(lib):
+        def run(y):                                  # launch per block (the form that takes a per-block row list)
+            bufs = [x, y[0], y[1]]
+            cur = 0
+            for i in range(NBLK):
+                nxt = 1 if cur != 1 else 2
+                assert lib.hive_nn_tower72(P(bufs[cur]), P(w[2 * i]), P(bias[2 * i]), P(bufs[nxt]), B, 1, DT[dtype], None, None, st()) == 0
+                cur = nxt
+            return bufs[cur]
+        return run
+
     for tag, lib in libs.items():
         sfx = f" [{tag}]" if tag else ""
         forms[f"resblock x {NBLK}" + sfx] = chain(lib)
         forms["tower 1 board/wg" + sfx] = tower(lib, 1)
         forms["tower 2 boards/wg 8 waves" + sfx] = tower(lib, 2)
         forms["tower 1 board/wg 1 wave/SIMD" + sfx] = tower(lib, 3)
+    if hasattr(L, "hive_nn_tower72"):
+        forms["tower72 asm (2 boards/wg, 72 tiles/wave)"] = tower72(L)
+        forms["tower72 asm, launch per block"] = tower72_chain(L)
     outs, times = {}, {k: [] for k in forms}
     ys = {k: [torch.zeros_like(x), torch.zeros_like(x)] for k in forms}
     for k, f in forms.items():
