@@ -25,24 +25,27 @@ PS = 544                      # LDS pixel stride in bytes (34 sixteen-byte slots
 NT, MT = 18, 4                # pixel tiles (both boards) x channel tiles per wave
 ZOFF = 288 * PS               # the zero pixel
 LDS_BYTES = 289 * PS
-D = 5                         # B-fragment LDS reads in flight
-BRING = 6                     # ring of B-fragment buffers
+D = 10                        # B-fragment LDS reads in flight
+BRING = 12                    # ring of B-fragment buffers (it lives in the epilogues' temporaries: the phases never overlap)
 ARING, AD = 4, 3              # ring of weight buffers; k-steps the weights are fetched ahead
 ROW_BYTES = 144 * 256 * 2     # one board in global memory
 KSTEP_BYTES = 16 * 1024       # one k-step of packed weights (16 fragments of 1 KiB)
+NTP = 20                      # boffN is fetched as five 4-register loads: 18 offsets + 2 pad
+TAP_BYTES = (NTP // 4) * 1024 # one tap of the offset table: [group of 4 tiles][lane][4] uint32
 
 # ---- register map -------------------------------------------------------------------------------------------------
 V_TID = 0
 V_WLANE = 1                   # wave * 4096 + lane * 16: this lane's byte offset inside a k-step's fragments
-V_TAB = 2                     # lane * 4
+V_TAB = 2                     # lane * 16
 V_BOFF = 4                    # 18 (register tuples must start on even registers): LDS byte offset of this lane's fragment row of pixel tile nt under the current tap
-V_BOFFN = V_BOFF + NT         # 18: ... under the next tap
-V_A = V_BOFFN + NT            # 64: weight ring [ARING][MT][4]
-V_B = V_A + ARING * MT * 4    # 24: pixel-fragment ring [BRING][4]
-V_ACC = V_B + BRING * 4       # 32: accumulator tiles 64..71
+V_BOFFN = V_BOFF + NT         # 20: ... under the next tap
+V_A = V_BOFFN + NTP           # 64: weight ring [ARING][MT][4]
+V_ACC = V_A + ARING * MT * 4  # 32: accumulator tiles 64..71
 V_BIAS = V_ACC + 32           # 16: bias[mt][4]
 V_T = V_BIAS + 16             # 30: epilogue temporaries (3 sets of 10)
 V_SK = V_T + 30               # 32: skip operands in flight (4 batches x 4 tiles x 2)
+V_B = V_T                     # 40: pixel-fragment ring [BRING][4] -- the same registers as V_T / V_SK, used in the tap loops only
+assert BRING * 4 <= 30 + 32 and (8 * NT) % BRING == 0 and D < BRING    # (a tap body must end in the ring phase it started in)
 V_GO = V_SK + 32              # 4: global pixel offsets of the batches in flight
 V_LDSW = V_GO + 4             # 3: epilogue LDS write bases
 V_GOFF = V_LDSW + 3           # 1: lr * 512 + lg * 8 + wave * 128
@@ -52,7 +55,7 @@ V_END = V_TMP + 4
 assert V_END <= 256, V_END
 NEXT_VGPR = (V_END + 7) // 8 * 8
 V_STAGE = V_A                 # 144 registers of staging data (prologue only; everything above V_A is dead then)
-assert V_STAGE + 144 <= 256
+assert V_STAGE + 144 <= V_GO
 
 S_KARG = 0
 S_WG = 2
@@ -142,19 +145,25 @@ class Asm:
 
 
 def tap_table():
-    """tab[tap][nt][lane]: LDS byte offset of lane's B-fragment row (pixel nt*16 + lane%16 shifted by the tap, k-group lane/16)."""
+    """tab[tap][group][lane][4]: LDS byte offsets of lane's B-fragment rows of pixel tiles 4 group .. 4 group + 3 (pixel
+    nt * 16 + lane % 16 shifted by the tap, k-group lane / 16); tiles 18, 19 are padding."""
     out = []
     for tap in range(9):
         dy, dx = tap // 3 - 1, tap % 3 - 1
-        for nt in range(NT):
-            slot, pt = divmod(nt, 9)
+        for grp in range(NTP // 4):
             for lane in range(64):
-                lr, lg = lane & 15, lane >> 4
-                pixel = pt * 16 + lr
-                y0, x0 = divmod(pixel, 12)
-                sy, sx = y0 + dy, x0 + dx
-                inb = 0 <= sy < 12 and 0 <= sx < 12
-                out.append(((slot * 144 + sy * 12 + sx) * PS if inb else ZOFF) + lg * 16)
+                for j in range(4):
+                    nt = grp * 4 + j
+                    if nt >= NT:
+                        out.append(ZOFF)
+                        continue
+                    slot, pt = divmod(nt, 9)
+                    lr, lg = lane & 15, lane >> 4
+                    pixel = pt * 16 + lr
+                    y0, x0 = divmod(pixel, 12)
+                    sy, sx = y0 + dy, x0 + dx
+                    inb = 0 <= sy < 12 and 0 <= sx < 12
+                    out.append(((slot * 144 + sy * 12 + sx) * PS if inb else ZOFF) + lg * 16)
     return out
 
 
@@ -191,6 +200,8 @@ def gen_kernel(name, dt, debug=0):
     e("s_cselect_b64 %s, 0, -1" % sr(S_HAS1, 2))      # exec mask of the second board's stores: nothing if it is a repeat
     e("s_cmp_eq_u64 %s, 0" % sr(S_IDX, 2))
     e("s_cbranch_scc1 .L%s_rows" % name)
+    if debug == 5:
+        e("s_branch .L%s_rows" % name)
     e("s_lshl_b32 %s, %s, 2" % (sr(S_T1), sr(S_R0)))
     e("s_lshl_b32 %s, %s, 2" % (sr(S_T2), sr(S_R1)))
     e("s_load_dword %s, %s, %s" % (sr(S_R0), sr(S_IDX, 2), sr(S_T1)))
@@ -211,7 +222,7 @@ def gen_kernel(name, dt, debug=0):
     e("v_and_b32_e32 %s, 63, %s" % (vr(LANE), vr(V_TID)))
     e("v_and_b32_e32 %s, 15, %s" % (vr(LR), vr(V_TID)))
     e("v_bfe_u32 %s, %s, 4, 2" % (vr(LG), vr(V_TID)))
-    e("v_lshlrev_b32_e32 %s, 2, %s" % (vr(V_TAB), vr(LANE)))
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(V_TAB), vr(LANE)))
     e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(V_WLANE), vr(LANE)))
     e("s_lshl_b32 %s, %s, 12" % (sr(S_T1), sr(S_WAVE)))
     e("v_add_u32_e32 %s, %s, %s" % (vr(V_WLANE), sr(S_T1), vr(V_WLANE)))
@@ -258,8 +269,6 @@ def gen_kernel(name, dt, debug=0):
     for i in range(4):
         e("v_mov_b32_e32 %s, 0" % vr(ZR + i))
     A.lg("ds_write_b128 %s, %s" % (vr(V_TMP), vr(ZR, 4)), ("zero",))
-    for i in range(256):
-        e("v_accvgpr_write_b32 a%d, 0" % i)
     for k in range(36):
         s_, j = divmod(k, 18)
         cst = (8 * j + 144 * s_) * PS
@@ -272,9 +281,6 @@ def gen_kernel(name, dt, debug=0):
         A.lg("ds_write_b128 %s, %s offset:%d" % (addr, vr(V_STAGE + 4 * k, 4), lo), ("stw", k))
         if len(A.lg_q) > 12:
             A.wait(lg_tag=A.lg_q[-8])
-    e("s_nop 1")                                 # (a 16-byte LDS write's data registers must not be rewritten at once)
-    for i in range(32):                          # (after the staging data has left these registers)
-        e("v_mov_b32_e32 %s, 0" % vr(V_ACC + i))
 
     def dump_lds_and_stop():
         A.drain()
@@ -344,64 +350,75 @@ def gen_kernel(name, dt, debug=0):
     # =============================================================== one convolution
     def conv(tag):
         c("---- convolution %s: 9 taps x 8 k-steps x (18 pixel tiles x 4 channel tiles)" % tag)
-        T = Asm()                                # the tap body is generated in its steady state
-        T.lines = A.lines
         c("tap 0 offsets -> boff; table pointer -> tap 1")
-        for nt in range(NT):
-            A.vm("global_load_dword %s, %s, %s offset:%d" % (vr(V_BOFF + nt), vr(V_TAB), sr(S_TAB, 2), nt * 256 - 2048), ("T0", nt))
-        e("s_add_u32 %s, %s, 0x%x" % (sr(S_TP), sr(S_TAB), NT * 256))
+        for grp in range(NTP // 4):
+            n = 4 if grp * 4 + 4 <= NT else NT - grp * 4      # (the padded entries of the last group go to the first boffN registers)
+            dst = V_BOFF + grp * 4
+            if n == 4:
+                A.vm("global_load_dwordx4 %s, %s, %s offset:%d" % (vr(dst, 4), vr(V_TAB), sr(S_TAB, 2), grp * 1024 - 2048), ("T0", grp))
+            else:
+                A.vm("global_load_dwordx4 %s, %s, %s offset:%d" % (vr(dst, 4), vr(V_TAB), sr(S_TAB, 2), grp * 1024 - 2048), ("T0", grp))
+        e("s_add_u32 %s, %s, 0x%x" % (sr(S_TP), sr(S_TAB), TAP_BYTES))
         e("s_addc_u32 %s, %s, 0" % (sr(S_TP + 1), sr(S_TAB + 1)))
-        e("s_mov_b32 %s, 0" % sr(S_TAP))
+        e("s_mov_b32 %s, 1" % sr(S_TAP))
         A.drain(vm=True, lg=False)
         for g in range(D):
-            A.lg("ds_read_b128 %s, %s" % (vr(V_B + (g % BRING) * 4, 4), vr(V_BOFF + g)), ("B", g))
+            A.lg("ds_read_b128 %s, %s%s" % (vr(V_B + (g % BRING) * 4, 4), vr(V_BOFF + g % NT),
+                                            " offset:%d" % ((g // NT) * 64) if g // NT else ""), ("B", g))
+
+        def tap_body(first):
+            T = Asm()                                # generated in its steady state: the queues as every iteration finds them
+            T.lines = A.lines
+            T.vm_q = [("A", j, mt) for j in range(AD) for mt in range(MT)]
+            T.lg_q = [("B", g) for g in range(D)]
+            for f in range(8 * NT):
+                kc, nt = divmod(f, NT)
+                if nt == 0:
+                    T.wait(vm_tag=("A", kc, MT - 1))
+                g = f + D
+                kcg, ntg = divmod(g, NT)
+                # (reads of k-step 8 belong to the next tap's first k-step: boff[ntg] holds the next tap's offset by then)
+                T.lg("ds_read_b128 %s, %s%s" % (vr(V_B + (g % BRING) * 4, 4), vr(V_BOFF + ntg),
+                                                " offset:%d" % ((kcg % 8) * 64) if kcg % 8 else ""), ("B", g))
+                if kcg == 7:
+                    T.wait(vm_tag=("T", ntg // 4))
+                    T.e("v_mov_b32_e32 %s, %s" % (vr(V_BOFF + ntg), vr(V_BOFFN + ntg)))
+                T.wait(lg_tag=("B", f))
+                for mt in range(MT):
+                    t = nt * MT + mt
+                    T.e("%s %s, %s, %s, %s" % (mfma, acc_reg(t), vr(V_A + ((kc % ARING) * MT + mt) * 4, 4),
+                                                 vr(V_B + (f % BRING) * 4, 4), "0" if first and kc == 0 else acc_reg(t)))
+                    if kc == 0 and mt == 1 and nt < NTP // 4:
+                        T.vm("global_load_dwordx4 %s, %s, %s offset:%d" % (vr(V_BOFFN + nt * 4, 4), vr(V_TAB), sr(S_TP, 2),
+                                                                          nt * 1024 - 2048), ("T", nt))
+                    if nt in (2, 6, 10, 14) and mt == 2:
+                        m = (nt - 2) // 4
+                        T.vm("global_load_dwordx4 %s, %s, %s offset:%d" % (vr(V_A + (((kc + AD) % ARING) * MT + m) * 4, 4),
+                                                                          vr(V_WLANE), sr(S_WP, 2), m * 1024), ("A", kc + AD, m))
+                if nt == 16:
+                    T.comment("advance the weight pointer by one k-step unless it already points at the last one")
+                    T.e("s_cmp_lg_u32 %s, 0" % sr(S_WLEFT))
+                    T.e("s_cselect_b32 %s, 0x%x, 0" % (sr(S_T0), KSTEP_BYTES))
+                    T.e("s_cselect_b32 %s, 1, 0" % sr(S_T1))
+                    T.e("s_add_u32 %s, %s, %s" % (sr(S_WP), sr(S_WP), sr(S_T0)))
+                    T.e("s_addc_u32 %s, %s, 0" % (sr(S_WP + 1), sr(S_WP + 1)))
+                    T.e("s_sub_u32 %s, %s, %s" % (sr(S_WLEFT), sr(S_WLEFT), sr(S_T1)))
+            # steady state reached again?
+            assert T.vm_q == [("A", 8 + j, mt) for j in range(AD) for mt in range(MT)], T.vm_q
+            assert T.lg_q == [("B", 8 * NT + g) for g in range(D)], T.lg_q
+            T.comment("next tap: table pointer (wraps to tap 0 after the last one: those offsets are fetched and never used)")
+            T.e("s_add_u32 %s, %s, 1" % (sr(S_TAP), sr(S_TAP)))
+            T.e("s_add_u32 %s, %s, 0x%x" % (sr(S_TP), sr(S_TP), TAP_BYTES))
+            T.e("s_addc_u32 %s, %s, 0" % (sr(S_TP + 1), sr(S_TP + 1)))
+            T.e("s_cmp_eq_u32 %s, 9" % sr(S_TAP))
+            T.e("s_cselect_b32 %s, %s, %s" % (sr(S_TP), sr(S_TAB), sr(S_TP)))
+            T.e("s_cselect_b32 %s, %s, %s" % (sr(S_TP + 1), sr(S_TAB + 1), sr(S_TP + 1)))
+
+        c("tap 0, peeled: its first k-step starts every accumulator from the constant 0 (no zeroing pass anywhere)")
+        tap_body(True)
         A.label(".L%s_%s_tap" % (name, tag))
-        T.vm_q = [("A", j, mt) for j in range(AD) for mt in range(MT)]
-        T.lg_q = [("B", g) for g in range(D)]
-        for f in range(8 * NT):
-            kc, nt = divmod(f, NT)
-            if nt == 0:
-                T.wait(vm_tag=("A", kc, MT - 1))
-            g = f + D
-            kcg, ntg = divmod(g, NT)
-            if kcg == 8:
-                pass                                 # (boff[ntg] already holds the next tap's offset: moved after read (7, ntg))
-            T.lg("ds_read_b128 %s, %s%s" % (vr(V_B + (g % BRING) * 4, 4), vr(V_BOFF + ntg),
-                                            " offset:%d" % ((kcg % 8) * 64) if kcg % 8 else ""), ("B", g))
-            if kcg == 7:
-                T.wait(vm_tag=("T", ntg))
-                T.e("v_mov_b32_e32 %s, %s" % (vr(V_BOFF + ntg), vr(V_BOFFN + ntg)))
-            T.wait(lg_tag=("B", f))
-            for mt in range(MT):
-                t = nt * MT + mt
-                T.e("%s %s, %s, %s, %s" % (mfma, acc_reg(t), vr(V_A + ((kc % ARING) * MT + mt) * 4, 4),
-                                             vr(V_B + (f % BRING) * 4, 4), acc_reg(t)))
-                if kc == 0 and mt == 1:
-                    T.vm("global_load_dword %s, %s, %s offset:%d" % (vr(V_BOFFN + nt), vr(V_TAB), sr(S_TP, 2), nt * 256 - 2048),
-                         ("T", nt))
-                if nt in (2, 6, 10, 14) and mt == 2:
-                    m = (nt - 2) // 4
-                    T.vm("global_load_dwordx4 %s, %s, %s offset:%d" % (vr(V_A + (((kc + AD) % ARING) * MT + m) * 4, 4), vr(V_WLANE),
-                                                                      sr(S_WP, 2), m * 1024), ("A", kc + AD, m))
-            if nt == 16:
-                c("advance the weight pointer by one k-step unless it already points at the last one")
-                T.e("s_cmp_lg_u32 %s, 0" % sr(S_WLEFT))
-                T.e("s_cselect_b32 %s, 0x%x, 0" % (sr(S_T0), KSTEP_BYTES))
-                T.e("s_cselect_b32 %s, 1, 0" % sr(S_T1))
-                T.e("s_add_u32 %s, %s, %s" % (sr(S_WP), sr(S_WP), sr(S_T0)))
-                T.e("s_addc_u32 %s, %s, 0" % (sr(S_WP + 1), sr(S_WP + 1)))
-                T.e("s_sub_u32 %s, %s, %s" % (sr(S_WLEFT), sr(S_WLEFT), sr(S_T1)))
-        # steady state reached again?
-        assert T.vm_q == [("A", 8 + j, mt) for j in range(AD) for mt in range(MT)], T.vm_q
-        assert T.lg_q == [("B", 8 * NT + g) for g in range(D)], T.lg_q
-        c("next tap: table pointer (wraps to tap 0 after the last one: those offsets are fetched and never used)")
-        e("s_add_u32 %s, %s, 1" % (sr(S_TAP), sr(S_TAP)))
-        e("s_add_u32 %s, %s, 0x%x" % (sr(S_TP), sr(S_TP), NT * 256))
-        e("s_addc_u32 %s, %s, 0" % (sr(S_TP + 1), sr(S_TP + 1)))
-        e("s_cmp_eq_u32 %s, 8" % sr(S_TAP))
-        e("s_cselect_b32 %s, %s, %s" % (sr(S_TP), sr(S_TAB), sr(S_TP)))
-        e("s_cselect_b32 %s, %s, %s" % (sr(S_TP + 1), sr(S_TAB + 1), sr(S_TP + 1)))
-        e("s_cmp_lt_u32 %s, 9" % sr(S_TAP))
+        tap_body(False)
+        e("s_cmp_lt_u32 %s, 10" % sr(S_TAP))
         e("s_cbranch_scc1 .L%s_%s_tap" % (name, tag))
         c("drain the stray fragment reads, let the last MFMAs retire")
         e("s_waitcnt lgkmcnt(0)")
@@ -410,29 +427,58 @@ def gen_kernel(name, dt, debug=0):
         A.vm_q, A.lg_q = [], []                      # (the A prefetches in flight are drained by the epilogue's vmcnt(0))
 
     def tile_src(t, tmp):
-        """Accumulator tile t -> four consecutive VGPRs holding it (reads AGPR tiles into tmp and re-zeroes the tile)."""
+        """Accumulator tile t -> four consecutive VGPRs holding it (AGPR tiles are read into tmp)."""
         if t < 64:
             for i in range(4):
                 e("v_accvgpr_read_b32 %s, a%d" % (vr(tmp + i), 4 * t + i))
-            for i in range(4):
-                e("v_accvgpr_write_b32 a%d, 0" % (4 * t + i))
-            return tmp, False
-        return V_ACC + 4 * (t - 64), True
+            return tmp
+        return V_ACC + 4 * (t - 64)
 
     def bias_loads(extra):
         for mt in range(MT):
             A.vm("global_load_dwordx4 %s, %s, %s offset:%d" % (vr(V_BIAS + 4 * mt, 4), vr(V_BIASOFF), sr(S_BP, 2), mt * 64 + extra),
                  ("bias", mt))
 
+    S_STAMP = 50                                     # pair: s_memtime value; S_SP = 52: pair: where this workgroup's stamps go
+
+    def stamp(k):
+        """DEBUG 5: wave 0 stores s_memtime at point k of the block (the queues are empty at every call site)."""
+        if debug != 5:
+            return
+        e("s_memtime %s" % sr(S_STAMP, 2))
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_cmp_lg_u32 %s, 0" % sr(S_WAVE))
+        e("s_cbranch_scc1 .L%s_nostamp%d" % (name, stamp.n))
+        pair, adr = V_GO, V_GO + 2                   # (free registers: an even pair + one)
+        e("v_mov_b32_e32 %s, %s" % (vr(pair), sr(S_STAMP)))
+        e("v_mov_b32_e32 %s, %s" % (vr(pair + 1), sr(S_STAMP + 1)))
+        e("v_mov_b32_e32 %s, 0" % vr(adr))
+        e("global_store_dwordx2 %s, %s, %s offset:%d" % (vr(adr), vr(pair, 2), sr(52, 2), 8 * k))
+        e("s_waitcnt vmcnt(0)")
+        A.label(".L%s_nostamp%d" % (name, stamp.n))
+        stamp.n += 1
+    stamp.n = 0
+
+    if debug == 5:
+        c("DEBUG 5: stamps go to rows[] (the row list is ignored by this build): [workgroup][block][16] uint64")
+        e("s_mul_i32 %s, %s, %s" % (sr(S_T1), sr(S_WG), sr(S_NBLK)))
+        e("s_lshl_b32 %s, %s, 7" % (sr(S_T1), sr(S_T1)))
+        e("s_add_u32 52, %s, %s" % (sr(S_IDX), sr(S_T1)) if False else "s_add_u32 s52, %s, %s" % (sr(S_IDX), sr(S_T1)))
+        e("s_addc_u32 s53, %s, 0" % sr(S_IDX + 1))
     A.label(".L%s_block" % name)
+    stamp(0)
     if debug == 2:
         c("DEBUG 2: no convolutions -- epilogue 2 on zero accumulators: y = relu(b2 + x)")
         e("s_branch .L%s_epi2" % name)
     # =============================================================== conv1 + epilogue 1
     conv("c1")
     c("---- epilogue 1: relu(acc + b1) -> 16 bits -> over the boards in LDS")
+    stamp(1)
     bias_loads(0)
     e("s_barrier")                                   # every wave has finished reading the block's input from LDS
+    if debug == 5:
+        A.drain()
+        stamp(2)
     A.wait(vm_tag=("bias", MT - 1))
     k = 0
     for nt in range(NT):
@@ -440,12 +486,9 @@ def gen_kernel(name, dt, debug=0):
             t = nt * MT + mt
             tmp = V_T + 10 * (k % 3)
             k += 1
-            src, is_v = tile_src(t, tmp)
+            src = tile_src(t, tmp)
             e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 4, 2), vr(src, 2), vr(V_BIAS + 4 * mt, 2)))
             e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 6, 2), vr(src + 2, 2), vr(V_BIAS + 4 * mt + 2, 2)))
-            if is_v:
-                for i in range(4):
-                    e("v_mov_b32_e32 %s, 0" % vr(src + i))
             for i in range(4):
                 e("v_max_f32_e32 %s, 0, %s" % (vr(tmp + 4 + i), vr(tmp + 4 + i)))
             e("%s %s, %s, %s" % (cvt, vr(tmp + 8), vr(tmp + 4), vr(tmp + 5)))
@@ -454,7 +497,9 @@ def gen_kernel(name, dt, debug=0):
                 A.wait(lg_tag=A.lg_q[-3])            # (the temporaries of three tiles ago are free again)
             A.lg("ds_write_b64 %s, %s offset:%d" % (vr(V_LDSW + nt // 7), vr(tmp + 8, 2), (nt % 7) * 16 * PS + mt * 32), ("w1", t))
     A.drain()
+    stamp(3)
     e("s_barrier")                                   # the intermediate boards are complete
+    stamp(4)
     if debug == 3:
         c("DEBUG 3: the intermediate boards (relu(conv1 + b1)) back out, stop")
         return dump_lds_and_stop()
@@ -463,66 +508,135 @@ def gen_kernel(name, dt, debug=0):
     conv("c2")
     A.label(".L%s_epi2" % name)
     c("---- epilogue 2: relu(acc + b2 + skip) -> 16 bits -> Y (the next block's skip operand) and LDS (its input)")
+    stamp(5)
     bias_loads(1024)
     e("s_barrier")                                   # every wave has finished reading the intermediate boards
+    if debug == 5:
+        A.drain()
+        stamp(6)
 
-    def skip_loads(nt):
-        slot, pt = divmod(nt, 9)
-        go = V_GO + nt % 4
-        e("v_add_u32_e32 %s, 0x%x, %s" % (vr(go), pt * 8192, vr(V_GOFF)))
-        for mt in range(MT):
-            A.vm("global_load_dwordx2 %s, %s, %s offset:%d" % (vr(V_SK + (nt % 4) * 8 + mt * 2, 2), vr(go),
-                                                               sr(S_SKIP1 if slot else S_SKIP0, 2), mt * 32), ("skip", nt, mt))
+    # The skip operand and the block's output cross the LDS image, so that every global access is a whole 16-byte piece of
+    # a contiguous 1-KiB run per wave-instruction (the accumulator layout holds 8-byte pieces of 16 different pixels per
+    # instruction: as direct loads / stores they cost 23 k of a block's 209 k cycles, in-kernel stamps of round 4):
+    #   1. x (the block's input) -> LDS image, coalesced, like the prologue's staging (the intermediate boards are dead now)
+    #   2. per accumulator tile: skip = the lane's own 8 bytes of the image; result written back to the same 8 bytes
+    #   3. LDS image (= the next block's input) -> Y, coalesced; no barrier after it: the next convolution only reads LDS
+    GROUPS = [V_BOFF + 4 * i for i in range((NT + NTP) // 4)] + [V_T + 4 * i for i in range((30 + 32) // 4)]
+    assert len(GROUPS) >= 18
+    ST_ADDR, ST_G = V_TMP + 2, V_TMP + 3
+    e("v_lshrrev_b32_e32 %s, 5, %s" % (vr(ST_ADDR), vr(V_TID)))
+    e("v_mul_u32_u24_e32 %s, 0x%x, %s" % (vr(ST_ADDR), PS, vr(ST_ADDR)))
+    e("v_and_b32_e32 %s, 31, %s" % (vr(V_TMP), vr(V_TID)))
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(V_TMP), vr(V_TMP)))
+    e("v_add_u32_e32 %s, %s, %s" % (vr(ST_ADDR), vr(ST_ADDR), vr(V_TMP)))
+    e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(ST_G), vr(V_TID)))
 
-    for nt in range(3):
-        skip_loads(nt)
-    k = 0
-    for nt in range(NT):
-        if nt + 3 < NT:
-            skip_loads(nt + 3)
-        slot = nt // 9
-        go = V_GO + nt % 4
-        for mt in range(MT):
-            t = nt * MT + mt
-            tmp = V_T + 10 * (k % 3)
-            k += 1
-            if nt == 0 and mt == 0:
-                A.wait(vm_tag=("bias", MT - 1))
-            src, is_v = tile_src(t, tmp)
-            e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 4, 2), vr(src, 2), vr(V_BIAS + 4 * mt, 2)))
-            e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 6, 2), vr(src + 2, 2), vr(V_BIAS + 4 * mt + 2, 2)))
-            if is_v:
-                for i in range(4):
-                    e("v_mov_b32_e32 %s, 0" % vr(src + i))
-            A.wait(vm_tag=("skip", nt, mt))
-            sk = V_SK + (nt % 4) * 8 + mt * 2
-            if dt == "bf16":
-                e("v_lshlrev_b32_e32 %s, 16, %s" % (vr(tmp + 0), vr(sk)))
-                e("v_and_b32_e32 %s, 0xffff0000, %s" % (vr(tmp + 1), vr(sk)))
-                e("v_lshlrev_b32_e32 %s, 16, %s" % (vr(tmp + 2), vr(sk + 1)))
-                e("v_and_b32_e32 %s, 0xffff0000, %s" % (vr(tmp + 3), vr(sk + 1)))
-            else:
-                e("v_cvt_f32_f16_e32 %s, %s" % (vr(tmp + 0), vr(sk)))
-                e("v_cvt_f32_f16_sdwa %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" % (vr(tmp + 1), vr(sk)))
-                e("v_cvt_f32_f16_e32 %s, %s" % (vr(tmp + 2), vr(sk + 1)))
-                e("v_cvt_f32_f16_sdwa %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" % (vr(tmp + 3), vr(sk + 1)))
-            e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 4, 2), vr(tmp + 4, 2), vr(tmp + 0, 2)))
-            e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 6, 2), vr(tmp + 6, 2), vr(tmp + 2, 2)))
-            for i in range(4):
-                e("v_max_f32_e32 %s, 0, %s" % (vr(tmp + 4 + i), vr(tmp + 4 + i)))
-            e("%s %s, %s, %s" % (cvt, vr(tmp + 8), vr(tmp + 4), vr(tmp + 5)))
-            e("%s %s, %s, %s" % (cvt, vr(tmp + 9), vr(tmp + 6), vr(tmp + 7)))
-            if len(A.lg_q) >= 3:
-                A.wait(lg_tag=A.lg_q[-3])
-            if slot:
-                e("s_mov_b64 exec, %s" % sr(S_HAS1, 2))
-            A.vm("global_store_dwordx2 %s, %s, %s offset:%d" % (vr(go), vr(tmp + 8, 2), sr(S_Y1 if slot else S_Y0, 2), mt * 32),
-                 ("st", t))
-            if slot:
-                e("s_mov_b64 exec, -1")
-            A.lg("ds_write_b64 %s, %s offset:%d" % (vr(V_LDSW + nt // 7), vr(tmp + 8, 2), (nt % 7) * 16 * PS + mt * 32), ("w2", t))
+    def image_addr(slot, j):
+        """(address register, immediate) of this thread's j-th 16-byte piece of board `slot` in the LDS image."""
+        cst = (8 * j + 144 * slot) * PS
+        hi, lo = cst // 32768 * 32768, cst % 32768
+        if hi:
+            e("v_add_u32_e32 %s, 0x%x, %s" % (vr(V_TMP + 1), hi, vr(ST_ADDR)))
+            return vr(V_TMP + 1), lo
+        return vr(ST_ADDR), lo
+
+    for slot, base in ((0, S_SKIP0), (1, S_SKIP1)):
+        e("s_mov_b64 %s, %s" % (sr(S_SRC, 2), sr(base, 2)))
+        for j in range(18):
+            if slot == 1:
+                # (this register group still feeds board 0's LDS write j: wait for that write to have been issued ...)
+                A.wait(vm_tag=("x", 0, j))
+                adr, lo = image_addr(0, j)
+                A.lg("ds_write_b128 %s, %s offset:%d" % (adr, vr(GROUPS[j], 4), lo), ("xw", 0, j))
+            A.vm("global_load_dwordx4 %s, %s, %s" % (vr(GROUPS[j], 4), vr(ST_G), sr(S_SRC, 2)), ("x", slot, j))
+            if j < 17:
+                e("s_add_u32 %s, %s, 0x1000" % (sr(S_SRC), sr(S_SRC)))
+                e("s_addc_u32 %s, %s, 0" % (sr(S_SRC + 1), sr(S_SRC + 1)))
+    for j in range(18):
+        A.wait(vm_tag=("x", 1, j))
+        adr, lo = image_addr(1, j)
+        A.lg("ds_write_b128 %s, %s offset:%d" % (adr, vr(GROUPS[j], 4), lo), ("xw", 1, j))
+    A.wait(vm_tag=("bias", MT - 1))
     A.drain()
-    e("s_barrier")                                   # the next block's input is complete
+    e("s_barrier")                                   # the image holds x
+    if debug == 5:
+        stamp(8)
+
+    AHEAD = 4                                        # skip reads in flight
+    tiles = [(nt, mt) for nt in range(NT) for mt in range(MT)]
+
+    def skip_read(i):
+        nt, mt = tiles[i]
+        A.lg("ds_read_b64 %s, %s offset:%d" % (vr(V_SK + (i % 8) * 2, 2), vr(V_LDSW + nt // 7), (nt % 7) * 16 * PS + mt * 32),
+             ("sk", i))
+
+    for i in range(AHEAD):
+        skip_read(i)
+    for i, (nt, mt) in enumerate(tiles):
+        if i + AHEAD < len(tiles):
+            skip_read(i + AHEAD)
+        t = nt * MT + mt
+        tmp = V_T + 10 * (i % 3)
+        src = tile_src(t, tmp)
+        e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 4, 2), vr(src, 2), vr(V_BIAS + 4 * mt, 2)))
+        e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 6, 2), vr(src + 2, 2), vr(V_BIAS + 4 * mt + 2, 2)))
+        A.wait(lg_tag=("sk", i))
+        sk = V_SK + (i % 8) * 2
+        if dt == "bf16":
+            e("v_lshlrev_b32_e32 %s, 16, %s" % (vr(tmp + 0), vr(sk)))
+            e("v_and_b32_e32 %s, 0xffff0000, %s" % (vr(tmp + 1), vr(sk)))
+            e("v_lshlrev_b32_e32 %s, 16, %s" % (vr(tmp + 2), vr(sk + 1)))
+            e("v_and_b32_e32 %s, 0xffff0000, %s" % (vr(tmp + 3), vr(sk + 1)))
+        else:
+            e("v_cvt_f32_f16_e32 %s, %s" % (vr(tmp + 0), vr(sk)))
+            e("v_cvt_f32_f16_sdwa %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" % (vr(tmp + 1), vr(sk)))
+            e("v_cvt_f32_f16_e32 %s, %s" % (vr(tmp + 2), vr(sk + 1)))
+            e("v_cvt_f32_f16_sdwa %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" % (vr(tmp + 3), vr(sk + 1)))
+        e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 4, 2), vr(tmp + 4, 2), vr(tmp + 0, 2)))
+        e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 6, 2), vr(tmp + 6, 2), vr(tmp + 2, 2)))
+        for k4 in range(4):
+            e("v_max_f32_e32 %s, 0, %s" % (vr(tmp + 4 + k4), vr(tmp + 4 + k4)))
+        e("%s %s, %s, %s" % (cvt, vr(tmp + 8), vr(tmp + 4), vr(tmp + 5)))
+        e("%s %s, %s, %s" % (cvt, vr(tmp + 9), vr(tmp + 6), vr(tmp + 7)))
+        A.lg("ds_write_b64 %s, %s offset:%d" % (vr(V_LDSW + nt // 7), vr(tmp + 8, 2), (nt % 7) * 16 * PS + mt * 32), ("w2", t))
+        # (the temporaries of this tile are rewritten three tiles on: by then its LDS write has long been issued)
+    A.drain()
+    e("s_barrier")                                   # the image holds the block's output = the next block's input
+    if debug == 5:
+        stamp(9)
+    c("image -> Y, sixteen bytes per lane, 1 KiB per wave-instruction")
+    PIPE = 9
+    order = [(slot, j) for slot in (0, 1) for j in range(18)]
+
+    def out_read(i):
+        slot, j = order[i]
+        adr, lo = image_addr(slot, j)
+        A.lg("ds_read_b128 %s, %s offset:%d" % (vr(GROUPS[i % 18], 4), adr, lo), ("or", i))
+
+    for i in range(PIPE):
+        out_read(i)
+    for i, (slot, j) in enumerate(order):
+        if j == 0:
+            e("s_mov_b64 %s, %s" % (sr(S_SRC, 2), sr(S_Y1 if slot else S_Y0, 2)))
+            if slot:
+                e("s_mov_b64 exec, %s" % sr(S_HAS1, 2))          # (a repeated tail board is stored once)
+        A.wait(lg_tag=("or", i))
+        A.vm("global_store_dwordx4 %s, %s, %s" % (vr(ST_G), vr(GROUPS[i % 18], 4), sr(S_SRC, 2)), ("st", i))
+        if j < 17:
+            e("s_add_u32 %s, %s, 0x1000" % (sr(S_SRC), sr(S_SRC)))
+            e("s_addc_u32 %s, %s, 0" % (sr(S_SRC + 1), sr(S_SRC + 1)))
+        if i + PIPE < len(order):
+            if i + PIPE >= 18:
+                A.wait(vm_tag=("st", i + PIPE - 18))             # (the register group's previous store has read its data)
+            out_read(i + PIPE)
+    e("s_mov_b64 exec, -1")
+    A.drain(vm=False, lg=True)
+    if debug == 5:
+        A.drain()
+    stamp(7)
+    if debug == 5:
+        e("s_add_u32 s52, s52, 128")
+        e("s_addc_u32 s53, s53, 0")
     c("next block: its skip operand is what was just stored")
     e("s_mov_b64 %s, %s" % (sr(S_SKIP0, 2), sr(S_Y0, 2)))
     e("s_mov_b64 %s, %s" % (sr(S_SKIP1, 2), sr(S_Y1, 2)))

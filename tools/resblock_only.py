@@ -1,5 +1,5 @@
 """Runs only the residual tower of a given build of csrc/hive_nn.hip (argv[1] = .so or "-" for the shipped library; argv[2] =
-0: launch-per-block chain (default), 1 / 2 / 3: hive_nn_tower's workgroup forms) 20 times at 1024 boards: the target of
+0: launch-per-block chain (default), 1 / 2 / 3: hive_nn_tower's workgroup forms, 72: hive_nn_tower72, the 72-tile assembly tower) 20 times at 1024 boards: the target of
 rocprofv3 --pmc passes that compare LDS strides / loop variants / launch forms."""
 import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +11,7 @@ L = ctypes.CDLL(so)
 vp, i32 = ctypes.c_void_p, ctypes.c_int
 L.hive_nn_resblock_dt.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
 L.hive_nn_tower.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+L.hive_nn_tower72.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
 B, NBLK = 1024, 19
 torch.manual_seed(0)
 x = torch.randn((B, 144, 256), device="cuda").to(torch.bfloat16)
@@ -19,6 +20,9 @@ bias = torch.randn((2 * NBLK, 256), device="cuda") * 0.1
 bufs = [x, torch.empty_like(x), torch.empty_like(x)]
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 def chain():
+    if mode == 72:
+        assert L.hive_nn_tower72(P(x), P(w), P(bias), P(bufs[1]), B, NBLK, _lib.BF16, None, None, None) == 0
+        return
     if mode:
         assert L.hive_nn_tower(P(x), P(w), P(bias), P(bufs[1]), B, NBLK, _lib.BF16, mode, None) == 0
         return
