@@ -425,6 +425,7 @@ class InferenceNet:
         # large leaf batches: let PyTorch's TunableOp pick the hipBLASLt solutions of the head GEMMs once, before the graph
         # is captured (the default heuristic runs the 1024 x 18432 x 1584 policy FC at 178 us, the tuned pick at 92 us)
         self.tune_gemms = tune_gemms and dev.type == "cuda"
+        self.hip_heads = conv == "hip"   # the heads on hive_nn_heads (False: the library GEMMs, as the fp32 path)
         self.fuse_blocks = True          # hive_nn_resblock: both convolutions of a residual block in one launch
         self.split_streams = True        # leaf batches >= 512: two independent half-batch chains on two streams
         self._side_stream = None
@@ -538,6 +539,23 @@ class InferenceNet:
         out["fc"] = (wfc.to(dev, dtype).contiguous(), ob.fc.bias.detach().to(dev, dtype))
         out["fc1"] = (ob.fc1.weight.detach().to(dev, torch.float32), ob.fc1.bias.detach().to(dev, torch.float32))
         out["fc2"] = (ob.fc2.weight.detach().to(dev, torch.float32), ob.fc2.bias.detach().to(dev, torch.float32))
+        if conv == "hip":
+            # hive_nn_heads (include/hive_nn.h): both 1x1 convolutions as one [144 x 256] matrix of MFMA A fragments (rows
+            # 0..127 policy, 128 value, the rest zero), the policy FC as B fragments over k = pixel * 128 + channel
+            wc = torch.zeros((144, 256), dtype=torch.float32, device=wp.device)
+            wc[:128] = wp.reshape(128, 256)
+            wc[128] = wv.reshape(256)
+            bc = torch.zeros((144,), dtype=torch.float32, device=wp.device)
+            bc[:128] = bp
+            bc[128] = bv.reshape(())
+            wc = wc.reshape(9, 16, 8, 4, 8).permute(0, 2, 3, 1, 4)          # M tile, k-step, k-group, row, 8
+            wf = wfc.reshape(99, 16, 576, 4, 8).permute(0, 2, 3, 1, 4)      # action tile, k-step, k-group, action % 16, 8
+            out["h_heads"] = (wc.to(dev, dtype).contiguous(), bc.to(dev).contiguous(), wf.to(dev, dtype).contiguous(),
+                              ob.fc.bias.detach().to(dev, torch.float32).contiguous(),
+                              ob.fc1.weight.detach().to(dev, torch.float32).t().contiguous(),      # [144][64]
+                              ob.fc1.bias.detach().to(dev, torch.float32).contiguous(),
+                              ob.fc2.weight.detach().to(dev, torch.float32).reshape(64).contiguous(),
+                              ob.fc2.bias.detach().to(dev, torch.float32).reshape(1).contiguous())
         return out
 
     def refresh(self, net):
@@ -694,6 +712,8 @@ class InferenceNet:
                 o = F.conv2d(o, w2, b2, padding=1)
                 s = F.relu(o + s)
         B = s.shape[0]
+        if self.conv == "hip" and self.hip_heads:
+            return self._heads_hip(s.permute(0, 2, 3, 1))
         flat = s.permute(0, 2, 3, 1).reshape(B * 144, 256)             # NHWC rows (a view: s is channels-last)
         v = F.relu(F.linear(flat, *self.vconv)).float().reshape(B, 144)
         v = F.relu(F.linear(v, *self.fc1))
@@ -701,6 +721,21 @@ class InferenceNet:
         p = F.relu(F.linear(flat, *self.pconv)).reshape(B, 144 * 128)  # NHWC flatten (matches self.fc columns)
         p = F.linear(p, *self.fc).float()
         return torch.softmax(p, dim=1), v
+
+    def _heads_hip(self, nhwc):
+        """Both heads on the hand-written kernels (hive_nn_heads): no library GEMM, nothing to tune at start-up."""
+        import ctypes
+        from ._lib import BF16, F16, check
+        assert nhwc.is_contiguous()
+        B = nhwc.shape[0]
+        ws = torch.empty((int(self._L.hive_nn_heads_workspace_bytes(B)),), dtype=torch.uint8, device=self.device)
+        p = torch.empty((B, ACTIONS), dtype=torch.float32, device=self.device)
+        v = torch.empty((B,), dtype=torch.float32, device=self.device)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        wc, bc, wf, bf_, w1, b1, w2, b2 = self.h_heads
+        check(self._L.hive_nn_heads(P(nhwc), B, BF16 if self.dtype == torch.bfloat16 else F16, P(wc), P(bc), P(wf), P(bf_), P(w1), P(b1),
+                                    P(w2), P(b2), P(ws), P(p), P(v), ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return p, v
 
     @torch.no_grad()
     def _tune(self, static_in):
@@ -754,7 +789,7 @@ class InferenceNet:
         if not self.use_graph:
             return self._forward(planes_hwc, need, rep)
         hip = self.conv == "hip"
-        key = (B, self.tower, self.fuse_blocks, self.split_streams)      # a captured graph keeps the launch form it saw
+        key = (B, self.tower, self.fuse_blocks, self.split_streams, self.hip_heads)      # a captured graph keeps the launch form it saw
         g = self._graphs.get(key)
         if g is None:
             static_in = torch.zeros_like(planes_hwc)
@@ -765,7 +800,7 @@ class InferenceNet:
                 s = torch.cuda.Stream(self.device)
                 s.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(s):
-                    if self.tune_gemms and B >= 256:
+                    if self.tune_gemms and B >= 256 and not (hip and self.hip_heads):
                         self._tune(static_in)
                     for _ in range(2):
                         self._forward(static_in, static_need, static_rep)

@@ -85,6 +85,24 @@ int hive_nn_tower72(const void *x, const void *w, const float *bias, void *y, in
 /* need int8[batch] (1 = evaluate) -> rows int32[batch] (indices of the flagged boards, ascending), *nrows = their number. */
 int hive_nn_compact_rows(const int8_t *need, int batch, int32_t *rows, int32_t *nrows, void *stream);
 
+/* The two heads of the network (alpha_net.py:56-80, OutBlock) on hand-written kernels -- no library GEMM in a forward:
+ *   x      [batch][144][256] the tower's output (dtype HIVE_BF16 / HIVE_F16), channels-last
+ *   wconv  [9][8][64][8]   both 1x1 convolutions (BatchNorm folded) as MFMA A fragments: rows 0..127 the policy convolution
+ *                          (alpha_net.py:62), row 128 the value convolution (:58), rows 129..143 zero; bconv f32 [144]
+ *   wfc    [99][576][64][8] the policy FC (:63) as MFMA B fragments: action tile, 32-deep k-step over k = pixel * 128 +
+ *                          channel, lane = (k % 32) / 8 * 16 + action % 16; bfc f32 [1584]
+ *   w1 f32 [144][64] (fc1's weight TRANSPOSED), b1 f32 [64], w2 f32 [64], b2 f32 [1]: the value MLP (:59-60)
+ *   workspace  hive_nn_heads_workspace_bytes(batch) bytes, 16-byte aligned, contents undefined between calls
+ *   p f32 [batch][1584] = softmax(policy logits), v f32 [batch] = tanh(value)
+ * Rounding points: the 1x1 convolutions' outputs are rounded to the 16-bit type (as 16-bit modules do); the FC accumulates
+ * in fp32 over K split into hive_nn_heads_splits(batch) ranges (a constant: a board's outputs do not depend on the batch it
+ * is evaluated in, nor on its position) summed in ascending order, and the softmax reads those fp32 logits. */
+int hive_nn_heads(const void *x, int batch, int dtype, const void *wconv, const float *bconv, const void *wfc, const float *bfc,
+                  const float *w1, const float *b1, const float *w2, const float *b2, void *workspace, float *p, float *v,
+                  void *stream);
+long long hive_nn_heads_workspace_bytes(int batch);
+int hive_nn_heads_splits(int batch);
+
 /* Training-mode BatchNorm2d + optional skip connection + optional ReLU of the 256-channel tower, forward and
  * backward (alpha_net.py:25-54 as executed by the training step alpha_net.py:117-162), channels-last bf16:
  *   forward : y = act( (x - mean_c) / sqrt(var_c + eps) * gamma_c + beta_c (+ residual) ), batch statistics over all

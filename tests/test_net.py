@@ -685,6 +685,68 @@ def test_reduced_precision_search_agrees_with_fp32_search():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_hip_heads_match_fp32_math_on_the_same_operands(dtype):
+    """hive_nn_heads (both 1x1 convolutions, the 18432 -> 1584 policy FC with softmax, the value MLP with tanh:
+    alpha_net.py:56-80) through the C ABI against the same arithmetic in fp64 on the same 16-bit operands with the same
+    rounding points (the convolutions' outputs rounded to the 16-bit type, everything else fp32 or better); a board's
+    outputs must not depend on the batch it sits in nor on its position (bit for bit), and repeat exactly."""
+    assert torch.cuda.is_available()
+    import ctypes
+    from hive_alphazero_amd import _lib
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    L = _lib.load()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    DT = _lib.BF16 if dtype == torch.bfloat16 else _lib.F16
+    torch.manual_seed(5)
+    net = ChessNet().cuda().eval()
+    with torch.no_grad():                      # heads with some contrast
+        net.outblock.fc.weight.mul_(20.0)
+        net.outblock.fc1.weight.mul_(5.0)
+        for bn in (net.outblock.bn, net.outblock.bn1):
+            bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5); bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+    inf = InferenceNet(net, dtype=dtype, use_graph=False)
+    wc, bc, wf, bf_, w1, b1, w2, b2 = inf.h_heads
+    gen = torch.Generator(device="cuda").manual_seed(6)
+
+    def run(x):
+        B = x.shape[0]
+        ws = torch.empty((int(L.hive_nn_heads_workspace_bytes(B)),), dtype=torch.uint8, device="cuda")
+        p = torch.empty((B, 1584), device="cuda")
+        v = torch.empty((B,), device="cuda")
+        _lib.check(L.hive_nn_heads(P(x), B, DT, P(wc), P(bc), P(wf), P(bf_), P(w1), P(b1), P(w2), P(b2), P(ws), P(p), P(v),
+                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        return p, v
+
+    x = torch.relu(torch.randn((37, 12, 12, 256), device="cuda", generator=gen)).to(dtype)
+    p, v = run(x)
+    # the same arithmetic in fp64 on the engine's own 16-bit weights
+    flat = x.reshape(37 * 144, 256).double()
+    pc = torch.relu((flat @ inf.pconv[0].double().t() + inf.pconv[1].double()).to(dtype)).double()     # bias as the engine holds it
+    bp32 = bc[:128].double()
+    pc = torch.relu((flat @ inf.pconv[0].double().t() + bp32).to(dtype)).double().reshape(37, 144 * 128)
+    logits = pc @ inf.fc[0].double().t() + bf_.double()
+    want_p = torch.softmax(logits, 1)
+    vc = torch.relu((flat @ inf.vconv[0].double().t() + bc[128].double()).to(dtype)).double().reshape(37, 144)
+    want_v = torch.tanh(torch.relu(vc @ w1.double() + b1.double()) @ w2.double() + b2.double())      # (w1 is stored transposed)
+    dp = float((p.double() - want_p).abs().max())
+    dl = float((torch.log(p.double() + 1e-30) - torch.log(want_p + 1e-30)).abs().max())
+    dv = float((v.double() - want_v).abs().max())
+    print(f"heads {dtype}: max |dp| {dp:.3g} (max p {float(want_p.max()):.3g}), max |d log p| {dl:.3g}, max |dv| {dv:.3g}")
+    # (a convolution output that falls on a rounding boundary may round the other way in fp32: a few 16-bit ulps of one input)
+    assert dl < 2e-2 and dv < 2e-3 and abs(float(p.sum(1).min()) - 1) < 1e-5
+    p2, v2 = run(x)
+    assert torch.equal(p, p2) and torch.equal(v, v2)
+    # position and batch independence, bit for bit: the 37 boards inside a batch of 1031, shifted by 500 rows
+    big = torch.relu(torch.randn((1031, 12, 12, 256), device="cuda", generator=gen)).to(dtype)
+    big[500:537] = x
+    pb, vb = run(big)
+    assert torch.equal(pb[500:537], p) and torch.equal(vb[500:537], v)
+    assert torch.isfinite(pb).all() and torch.isfinite(vb).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_hip_tower72_matches_resblock_chain(dtype):
     """hive_nn_tower72 (the 72-tile assembly tower: two boards per workgroup, 288 accumulator registers per lane,
     csrc/gen_tower_asm.py) against the launch-per-block chain hive_nn_resblock_dt, through the C ABI, bit for bit:
