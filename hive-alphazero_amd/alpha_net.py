@@ -587,16 +587,12 @@ class InferenceNet:
 
     def _tower_form(self, B):
         """The launch form of the 19 residual blocks for a batch of B boards: self.tower, with "auto" resolved.
-        The 72-tile tower (72) runs one 2-board workgroup per CU and a whole tower per workgroup, so its time is
-        ceil(B / 512) rounds of ~2.0 ms whatever part of the last round is filled (1024 boards: 4.00 ms against 4.76 ms for
-        the launch-per-block chain, profiles/r04_net_tower72.md); the chain's time is proportional to B.  auto = the tower
-        when its last round is at least 86 % full."""
+        The 72-tile tower (72: hive_nn_tower72_balanced, one 2-board workgroup per CU, the pairs' blocks dealt evenly over
+        the chip) costs ~3.9 us per evaluated board once the chip is full (220 pairs and more); the launch-per-block chain
+        costs ~4.6 us per board and wins below that (profiles/r04_net_tower72.md).  auto = the tower from 440 boards on."""
         if self.tower != "auto":
             return self.tower
-        if not self.fuse_blocks or B < 440:
-            return 0
-        rounds = -(-B // 512)
-        return 72 if B >= 0.86 * rounds * 512 else 0
+        return 72 if self.fuse_blocks and B >= 440 else 0
 
     def _tower_hip(self, x_hwc, need=None, rep=None):
         """need: int8[B] on the device or None -- boards flagged 0 are skipped by every kernel of the tower (their rows of
@@ -644,10 +640,12 @@ class InferenceNet:
                 nrows = torch.empty((1,), dtype=torch.int32, device=self.device)
                 check(self._L.hive_nn_compact_rows(ctypes.c_void_p(need.data_ptr()), B, ctypes.c_void_p(rows.data_ptr()),
                                                    ctypes.c_void_p(nrows.data_ptr()), st))
-            check(self._L.hive_nn_tower72(ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(tw.data_ptr()),
-                                          ctypes.c_void_p(tb.data_ptr()), ctypes.c_void_p(bufs[1].data_ptr()), B, 19, dt,
-                                          ctypes.c_void_p(rows.data_ptr()) if rows is not None else None,
-                                          ctypes.c_void_p(nrows.data_ptr()) if nrows is not None else None, st))
+            plan = torch.empty((int(self._L.hive_nn_tower72_plan_bytes(B)),), dtype=torch.uint8, device=self.device)
+            check(self._L.hive_nn_tower72_balanced(ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(tw.data_ptr()),
+                                                   ctypes.c_void_p(tb.data_ptr()), ctypes.c_void_p(bufs[1].data_ptr()), B, 19, dt,
+                                                   ctypes.c_void_p(rows.data_ptr()) if rows is not None else None,
+                                                   ctypes.c_void_p(nrows.data_ptr()) if nrows is not None else None,
+                                                   ctypes.c_void_p(plan.data_ptr()), st))
             return bufs[1].permute(0, 3, 1, 2)
         if tower:
             tw, tb = self.h_tower

@@ -24,7 +24,8 @@ import sys
 PS = 544                      # LDS pixel stride in bytes (34 sixteen-byte slots: the 16 lanes of a ds_read_b128 phase hit 16 slots)
 NT, MT = 18, 4                # pixel tiles (both boards) x channel tiles per wave
 ZOFF = 288 * PS               # the zero pixel
-LDS_BYTES = 289 * PS
+MAILBOX = 289 * PS            # one LDS word behind the image: wave 0's verdict of a hand-over poll
+LDS_BYTES = 289 * PS + 64
 D = 10                        # B-fragment LDS reads in flight
 BRING = 12                    # ring of B-fragment buffers (it lives in the epilogues' temporaries: the phases never overlap)
 ARING, AD = 4, 3              # ring of weight buffers; k-steps the weights are fetched ahead
@@ -75,8 +76,17 @@ S_WAVE = 40
 S_R0, S_R1 = 41, 42
 S_T1, S_T2, S_T3 = 43, 44, 45
 S_SRC = 46                    # pair: staging source
+S_PLAN = 18                   # pair: the launch plan (or null): per workgroup 8 ints + the hand-over flags behind them
+S_D = 56                      # 8: this workgroup's plan entry: head pair, head end block, first full pair, end of the full
+                              #    pairs, tail pair, tail first block, -, -
+S_PHASE, S_PAIR, S_B0, S_B1, S_MODE, S_POLL = 64, 65, 66, 67, 68, 69
+S_FLAG = 70                   # pair: address of the current pair's hand-over flag
+S_STG0, S_STG1 = 72, 74       # pairs: where the current segment's boards are staged from (X rows, or Y rows for a tail)
+PLAN_STRIDE = 32              # bytes per workgroup in the plan
+MAX_WG = 256                  # workgroups a plan covers; the flags start at plan + MAX_WG * PLAN_STRIDE
+BLOCK_W_BYTES = 2 * 72 * KSTEP_BYTES     # packed weights of one residual block
 S_HAS1 = 48                   # pair: exec mask for the second board's global stores (0 when the pair's second entry repeats the first)
-NEXT_SGPR = 56
+NEXT_SGPR = 80
 
 
 def acc_reg(t):
@@ -175,10 +185,10 @@ def gen_kernel(name, dt, debug=0):
     e, c = A.e, A.comment
 
     # =============================================================== prologue
-    c("kernarg: X W bias Y idx count | batch nblocks")
+    c("kernarg: X W bias Y idx count | batch nblocks | plan")
     e("s_load_dwordx8 %s, %s, 0x0" % (sr(S_X, 8), sr(S_KARG, 2)))
     e("s_load_dwordx4 %s, %s, 0x20" % (sr(S_IDX, 4), sr(S_KARG, 2)))
-    e("s_load_dwordx2 %s, %s, 0x30" % (sr(S_N, 2), sr(S_KARG, 2)))
+    e("s_load_dwordx4 %s, %s, 0x30" % (sr(S_N, 4), sr(S_KARG, 2)))
     e("v_lshrrev_b32_e32 %s, 6, %s" % (vr(V_TMP), vr(V_TID)))
     e("s_nop 1")                                 # (a VALU-written register is not yet visible to v_readfirstlane)
     e("v_readfirstlane_b32 %s, %s" % (sr(S_WAVE), vr(V_TMP)))
@@ -190,32 +200,23 @@ def gen_kernel(name, dt, debug=0):
     e("s_load_dword %s, %s, 0x0" % (sr(S_N), sr(S_CNT, 2)))
     e("s_waitcnt lgkmcnt(0)")
     A.label(".L%s_havecount" % name)
-    e("s_lshl_b32 %s, %s, 1" % (sr(S_R0), sr(S_WG)))
-    e("s_cmp_ge_u32 %s, %s" % (sr(S_R0), sr(S_N)))
-    e("s_cbranch_scc1 .L%s_end" % name)
-    c("second entry of the pair; an odd tail repeats the first board (its copy computes along and stores nothing)")
-    e("s_add_u32 %s, %s, 1" % (sr(S_R1), sr(S_R0)))
-    e("s_cmp_ge_u32 %s, %s" % (sr(S_R1), sr(S_N)))
-    e("s_cselect_b32 %s, %s, %s" % (sr(S_R1), sr(S_R0), sr(S_R1)))
-    e("s_cselect_b64 %s, 0, -1" % sr(S_HAS1, 2))      # exec mask of the second board's stores: nothing if it is a repeat
-    e("s_cmp_eq_u64 %s, 0" % sr(S_IDX, 2))
-    e("s_cbranch_scc1 .L%s_rows" % name)
-    if debug == 5:
-        e("s_branch .L%s_rows" % name)
-    e("s_lshl_b32 %s, %s, 2" % (sr(S_T1), sr(S_R0)))
-    e("s_lshl_b32 %s, %s, 2" % (sr(S_T2), sr(S_R1)))
-    e("s_load_dword %s, %s, %s" % (sr(S_R0), sr(S_IDX, 2), sr(S_T1)))
-    e("s_load_dword %s, %s, %s" % (sr(S_R1), sr(S_IDX, 2), sr(S_T2)))
+    c("this workgroup's work: its plan entry, or (no plan) the one pair of boards 2 wg, 2 wg + 1 through every block")
+    e("s_mov_b32 %s, -1" % sr(S_D + 0))
+    e("s_mov_b32 %s, 0" % sr(S_D + 1))
+    e("s_mov_b32 %s, %s" % (sr(S_D + 2), sr(S_WG)))
+    e("s_add_u32 %s, %s, 1" % (sr(S_D + 3), sr(S_WG)))
+    e("s_mov_b32 %s, -1" % sr(S_D + 4))
+    e("s_mov_b32 %s, 0" % sr(S_D + 5))
+    e("s_lshl_b32 %s, %s, 1" % (sr(S_T1), sr(S_WG)))
+    e("s_cmp_ge_u32 %s, %s" % (sr(S_T1), sr(S_N)))
+    e("s_cselect_b32 %s, %s, %s" % (sr(S_D + 3), sr(S_D + 2), sr(S_D + 3)))      # (nothing to do: an empty range of full pairs)
+    e("s_cmp_eq_u64 %s, 0" % sr(S_PLAN, 2))
+    e("s_cbranch_scc1 .L%s_planned" % name)
+    e("s_lshl_b32 %s, %s, %d" % (sr(S_T1), sr(S_WG), PLAN_STRIDE.bit_length() - 1))
+    e("s_load_dwordx8 %s, %s, %s" % (sr(S_D, 8), sr(S_PLAN, 2), sr(S_T1)))
     e("s_waitcnt lgkmcnt(0)")
-    A.label(".L%s_rows" % name)
-    c("row byte offsets (64 bit) -> skip (= X) and Y bases of the two boards")
-    for r, skip, yb in ((S_R0, S_SKIP0, S_Y0), (S_R1, S_SKIP1, S_Y1)):
-        e("s_mul_hi_u32 %s, %s, 0x%x" % (sr(S_T2), sr(r), ROW_BYTES))
-        e("s_mul_i32 %s, %s, 0x%x" % (sr(S_T1), sr(r), ROW_BYTES))
-        e("s_add_u32 %s, %s, %s" % (sr(skip), sr(S_X), sr(S_T1)))
-        e("s_addc_u32 %s, %s, %s" % (sr(skip + 1), sr(S_X + 1), sr(S_T2)))
-        e("s_add_u32 %s, %s, %s" % (sr(yb), sr(S_Y), sr(S_T1)))
-        e("s_addc_u32 %s, %s, %s" % (sr(yb + 1), sr(S_Y + 1), sr(S_T2)))
+    A.label(".L%s_planned" % name)
+    e("s_mov_b32 %s, 0" % sr(S_PHASE))
 
     c("lane constants")
     LANE, LR, LG = V_TMP + 1, V_TMP + 2, V_TMP + 3
@@ -244,6 +245,133 @@ def gen_kernel(name, dt, debug=0):
     e("s_add_u32 %s, %s, hive_tap_table@rel32@lo+2052" % (sr(S_TAB), sr(S_TAB)))
     e("s_addc_u32 %s, %s, hive_tap_table@rel32@hi+2060" % (sr(S_TAB + 1), sr(S_TAB + 1)))
 
+    # =============================================================== the workgroup's segments, one after the other
+    A.label(".L%s_next" % name)
+    c("phase 0: the head of a pair that another workgroup finishes (first, so that its successor never waits long)")
+    e("s_cmp_lg_u32 %s, 0" % sr(S_PHASE))
+    e("s_cbranch_scc1 .L%s_ph1" % name)
+    e("s_mov_b32 %s, 1" % sr(S_PHASE))
+    e("s_cmp_lt_i32 %s, 0" % sr(S_D + 0))
+    e("s_cbranch_scc1 .L%s_ph1" % name)
+    e("s_mov_b32 %s, %s" % (sr(S_PAIR), sr(S_D + 0)))
+    e("s_mov_b32 %s, 0" % sr(S_B0))
+    e("s_mov_b32 %s, %s" % (sr(S_B1), sr(S_D + 1)))
+    e("s_mov_b32 %s, 2" % sr(S_MODE))
+    e("s_branch .L%s_go" % name)
+    A.label(".L%s_ph1" % name)
+    c("phase 1: whole pairs")
+    e("s_cmp_lg_u32 %s, 1" % sr(S_PHASE))
+    e("s_cbranch_scc1 .L%s_ph2" % name)
+    e("s_cmp_ge_i32 %s, %s" % (sr(S_D + 2), sr(S_D + 3)))
+    e("s_cbranch_scc1 .L%s_ph1done" % name)
+    e("s_mov_b32 %s, %s" % (sr(S_PAIR), sr(S_D + 2)))
+    e("s_add_u32 %s, %s, 1" % (sr(S_D + 2), sr(S_D + 2)))
+    e("s_mov_b32 %s, 0" % sr(S_B0))
+    e("s_mov_b32 %s, %s" % (sr(S_B1), sr(S_NBLK)))
+    e("s_mov_b32 %s, 0" % sr(S_MODE))
+    e("s_branch .L%s_go" % name)
+    A.label(".L%s_ph1done" % name)
+    e("s_mov_b32 %s, 2" % sr(S_PHASE))
+    A.label(".L%s_ph2" % name)
+    c("phase 2: the tail of a pair whose head another workgroup computed first thing")
+    e("s_cmp_lg_u32 %s, 2" % sr(S_PHASE))
+    e("s_cbranch_scc1 .L%s_end" % name)
+    e("s_mov_b32 %s, 3" % sr(S_PHASE))
+    e("s_cmp_lt_i32 %s, 0" % sr(S_D + 4))
+    e("s_cbranch_scc1 .L%s_end" % name)
+    e("s_mov_b32 %s, %s" % (sr(S_PAIR), sr(S_D + 4)))
+    e("s_mov_b32 %s, %s" % (sr(S_B0), sr(S_D + 5)))
+    e("s_mov_b32 %s, %s" % (sr(S_B1), sr(S_NBLK)))
+    e("s_mov_b32 %s, 1" % sr(S_MODE))
+    A.label(".L%s_go" % name)
+    c("rows of the pair; an odd tail repeats the first board (its copy computes along and stores nothing)")
+    e("s_lshl_b32 %s, %s, 1" % (sr(S_R0), sr(S_PAIR)))
+    e("s_add_u32 %s, %s, 1" % (sr(S_R1), sr(S_R0)))
+    e("s_cmp_ge_u32 %s, %s" % (sr(S_R1), sr(S_N)))
+    e("s_cselect_b32 %s, %s, %s" % (sr(S_R1), sr(S_R0), sr(S_R1)))
+    e("s_cselect_b64 %s, 0, -1" % sr(S_HAS1, 2))      # exec mask of the second board's stores: nothing if it is a repeat
+    e("s_cmp_eq_u64 %s, 0" % sr(S_IDX, 2))
+    e("s_cbranch_scc1 .L%s_rows" % name)
+    if debug == 5:
+        e("s_branch .L%s_rows" % name)
+    e("s_lshl_b32 %s, %s, 2" % (sr(S_T1), sr(S_R0)))
+    e("s_lshl_b32 %s, %s, 2" % (sr(S_T2), sr(S_R1)))
+    e("s_load_dword %s, %s, %s" % (sr(S_R0), sr(S_IDX, 2), sr(S_T1)))
+    e("s_load_dword %s, %s, %s" % (sr(S_R1), sr(S_IDX, 2), sr(S_T2)))
+    e("s_waitcnt lgkmcnt(0)")
+    A.label(".L%s_rows" % name)
+    c("row byte offsets (64 bit) -> X and Y rows of the two boards")
+    for r, skip, yb in ((S_R0, S_SKIP0, S_Y0), (S_R1, S_SKIP1, S_Y1)):
+        e("s_mul_hi_u32 %s, %s, 0x%x" % (sr(S_T2), sr(r), ROW_BYTES))
+        e("s_mul_i32 %s, %s, 0x%x" % (sr(S_T1), sr(r), ROW_BYTES))
+        e("s_add_u32 %s, %s, %s" % (sr(skip), sr(S_X), sr(S_T1)))
+        e("s_addc_u32 %s, %s, %s" % (sr(skip + 1), sr(S_X + 1), sr(S_T2)))
+        e("s_add_u32 %s, %s, %s" % (sr(yb), sr(S_Y), sr(S_T1)))
+        e("s_addc_u32 %s, %s, %s" % (sr(yb + 1), sr(S_Y + 1), sr(S_T2)))
+    c("the previous segment's image -> Y reads of LDS are done in every wave before the image is overwritten")
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    e("s_barrier")
+    c("a tail starts from block b0 - 1's output (Y), written by another workgroup: wait for its flag, then acquire")
+    e("s_cmp_eq_u32 %s, 0" % sr(S_B0))
+    e("s_cbranch_scc1 .L%s_fromx" % name)
+    e("s_lshl_b32 %s, %s, 2" % (sr(S_T1), sr(S_PAIR)))
+    e("s_add_u32 %s, %s, 0x%x" % (sr(S_FLAG), sr(S_PLAN), MAX_WG * PLAN_STRIDE))
+    e("s_addc_u32 %s, %s, 0" % (sr(S_FLAG + 1), sr(S_PLAN + 1)))
+    e("s_add_u32 %s, %s, %s" % (sr(S_FLAG), sr(S_FLAG), sr(S_T1)))
+    e("s_addc_u32 %s, %s, 0" % (sr(S_FLAG + 1), sr(S_FLAG + 1)))
+    c("wave 0 polls (bounded); its verdict reaches the other waves through an LDS word, so that all four take the same path")
+    e("s_cmp_lg_u32 %s, 0" % sr(S_WAVE))
+    e("s_cbranch_scc1 .L%s_pollwait" % name)
+    e("s_mov_b32 %s, 0" % sr(S_POLL))
+    e("v_mov_b32_e32 %s, 0" % vr(V_TMP))
+    A.label(".L%s_poll" % name)
+    e("global_load_dword %s, %s, %s sc1" % (vr(V_TMP + 1), vr(V_TMP), sr(S_FLAG, 2)))
+    e("s_waitcnt vmcnt(0)")
+    e("v_readfirstlane_b32 %s, %s" % (sr(S_T1), vr(V_TMP + 1)))
+    e("s_nop 4")
+    e("s_cmp_ge_i32 %s, %s" % (sr(S_T1), sr(S_B0)))
+    e("s_cselect_b32 %s, %s, 0" % (sr(S_T2), sr(S_B0)))            # the verdict so far: b0 (flag seen) or 0
+    e("s_cbranch_scc1 .L%s_polled" % name)
+    e("s_sleep 32")
+    e("s_add_u32 %s, %s, 1" % (sr(S_POLL), sr(S_POLL)))
+    e("s_cmp_lt_u32 %s, 0x%x" % (sr(S_POLL), 1 << 19))
+    e("s_cbranch_scc1 .L%s_poll" % name)
+    c("(the head never came -- its workgroup is not running: verdict 0 = this workgroup computes the whole pair itself; both write the same bytes)")
+    A.label(".L%s_polled" % name)
+    e("v_mov_b32_e32 %s, %s" % (vr(V_TMP + 1), sr(S_T2)))
+    e("v_mov_b32_e32 %s, 0x%x" % (vr(V_TMP), MAILBOX))
+    e("ds_write_b32 %s, %s" % (vr(V_TMP), vr(V_TMP + 1)))
+    e("s_waitcnt lgkmcnt(0)")
+    A.label(".L%s_pollwait" % name)
+    e("s_barrier")
+    e("v_mov_b32_e32 %s, 0x%x" % (vr(V_TMP), MAILBOX))
+    e("ds_read_b32 %s, %s" % (vr(V_TMP + 1), vr(V_TMP)))
+    e("s_waitcnt lgkmcnt(0)")
+    e("v_readfirstlane_b32 %s, %s" % (sr(S_B0), vr(V_TMP + 1)))
+    e("s_nop 4")
+    e("s_cmp_eq_u32 %s, 0" % sr(S_B0))
+    e("s_cbranch_scc1 .L%s_fromx" % name)
+    A.label(".L%s_acquire" % name)
+    e("buffer_inv sc1")
+    e("s_waitcnt vmcnt(0)")
+    e("s_mov_b64 %s, %s" % (sr(S_SKIP0, 2), sr(S_Y0, 2)))
+    e("s_mov_b64 %s, %s" % (sr(S_SKIP1, 2), sr(S_Y1, 2)))
+    A.label(".L%s_fromx" % name)
+    e("s_mov_b64 %s, %s" % (sr(S_STG0, 2), sr(S_SKIP0, 2)))
+    e("s_mov_b64 %s, %s" % (sr(S_STG1, 2), sr(S_SKIP1, 2)))
+    c("this segment's blocks: weights, biases, counters")
+    e("s_mul_i32 %s, %s, 0x%x" % (sr(S_T1), sr(S_B0), BLOCK_W_BYTES))
+    e("s_mul_hi_u32 %s, %s, 0x%x" % (sr(S_T2), sr(S_B0), BLOCK_W_BYTES))
+    e("s_add_u32 %s, %s, %s" % (sr(S_WP), sr(S_W), sr(S_T1)))
+    e("s_addc_u32 %s, %s, %s" % (sr(S_WP + 1), sr(S_W + 1), sr(S_T2)))
+    e("s_lshl_b32 %s, %s, 11" % (sr(S_T1), sr(S_B0)))
+    e("s_add_u32 %s, %s, %s" % (sr(S_BP), sr(S_BIAS), sr(S_T1)))
+    e("s_addc_u32 %s, %s, 0" % (sr(S_BP + 1), sr(S_BIAS + 1)))
+    e("s_sub_u32 %s, %s, %s" % (sr(S_BLK), sr(S_B1), sr(S_B0)))
+    e("s_sub_u32 %s, %s, %s" % (sr(S_WLEFT), sr(S_NBLK), sr(S_B0)))
+    e("s_mul_i32 %s, %s, 144" % (sr(S_WLEFT), sr(S_WLEFT)))
+    e("s_sub_u32 %s, %s, %d" % (sr(S_WLEFT), sr(S_WLEFT), AD + 1))
+
     c("stage both boards: 36 sixteen-byte loads per thread, all in flight, then 36 LDS writes")
     ST_ADDR, ST_G = V_BOFF, V_BOFF + 1          # (V_BOFF.. are dead until the first convolution)
     e("v_lshrrev_b32_e32 %s, 5, %s" % (vr(ST_ADDR), vr(V_TID)))
@@ -252,7 +380,7 @@ def gen_kernel(name, dt, debug=0):
     e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(V_TMP), vr(V_TMP)))
     e("v_add_u32_e32 %s, %s, %s" % (vr(ST_ADDR), vr(ST_ADDR), vr(V_TMP)))
     e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(ST_G), vr(V_TID)))
-    for s_, base in ((0, S_SKIP0), (1, S_SKIP1)):
+    for s_, base in ((0, S_STG0), (1, S_STG1)):
         e("s_mov_b64 %s, %s" % (sr(S_SRC, 2), sr(base, 2)))
         for j in range(18):
             k = s_ * 18 + j
@@ -332,18 +460,13 @@ def gen_kernel(name, dt, debug=0):
         e("s_endpgm")
         return A.lines
 
-    c("weights: k-steps 0 .. AD-1 into ring buffers 0 .. AD-1; S_WP -> k-step AD; S_WLEFT = total k-steps - 1 - AD")
-    e("s_mov_b64 %s, %s" % (sr(S_WP, 2), sr(S_W, 2)))
+    c("weights: the segment's k-steps 0 .. AD-1 into ring buffers 0 .. AD-1; S_WP -> k-step AD")
     for j in range(AD):
         for mt in range(MT):
             A.vm("global_load_dwordx4 %s, %s, %s offset:%d" % (vr(V_A + (j * MT + mt) * 4, 4), vr(V_WLANE), sr(S_WP, 2), mt * 1024),
                  ("A0", j, mt))
         e("s_add_u32 %s, %s, 0x%x" % (sr(S_WP), sr(S_WP), KSTEP_BYTES))
         e("s_addc_u32 %s, %s, 0" % (sr(S_WP + 1), sr(S_WP + 1)))
-    e("s_mul_i32 %s, %s, 144" % (sr(S_WLEFT), sr(S_NBLK)))
-    e("s_sub_u32 %s, %s, %d" % (sr(S_WLEFT), sr(S_WLEFT), AD + 1))
-    e("s_mov_b64 %s, %s" % (sr(S_BP, 2), sr(S_BIAS, 2)))
-    e("s_mov_b32 %s, %s" % (sr(S_BLK), sr(S_NBLK)))
     A.drain()
     e("s_barrier")
 
@@ -645,6 +768,25 @@ def gen_kernel(name, dt, debug=0):
     e("s_sub_u32 %s, %s, 1" % (sr(S_BLK), sr(S_BLK)))
     e("s_cmp_lg_u32 %s, 0" % sr(S_BLK))
     e("s_cbranch_scc1 .L%s_block" % name)
+    c("a head hands its pair over: every wave's stores done, then one wave writes the L2 back and raises the pair's flag")
+    e("s_bitcmp1_b32 %s, 1" % sr(S_MODE))
+    e("s_cbranch_scc0 .L%s_next" % name)
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    e("s_barrier")
+    e("s_cmp_lg_u32 %s, 0" % sr(S_WAVE))
+    e("s_cbranch_scc1 .L%s_next" % name)
+    e("s_lshl_b32 %s, %s, 2" % (sr(S_T1), sr(S_PAIR)))
+    e("s_add_u32 %s, %s, 0x%x" % (sr(S_FLAG), sr(S_PLAN), MAX_WG * PLAN_STRIDE))
+    e("s_addc_u32 %s, %s, 0" % (sr(S_FLAG + 1), sr(S_PLAN + 1)))
+    e("s_add_u32 %s, %s, %s" % (sr(S_FLAG), sr(S_FLAG), sr(S_T1)))
+    e("s_addc_u32 %s, %s, 0" % (sr(S_FLAG + 1), sr(S_FLAG + 1)))
+    e("buffer_wbl2 sc1")
+    e("s_waitcnt vmcnt(0)")
+    e("v_mov_b32_e32 %s, 0" % vr(V_TMP))
+    e("v_mov_b32_e32 %s, %s" % (vr(V_TMP + 1), sr(S_B1)))
+    e("global_store_dword %s, %s, %s sc1" % (vr(V_TMP), vr(V_TMP + 1), sr(S_FLAG, 2)))
+    e("s_waitcnt vmcnt(0)")
+    e("s_branch .L%s_next" % name)
     A.label(".L%s_end" % name)
     e("s_endpgm")
     return A.lines
@@ -658,7 +800,7 @@ def kernel_text(name, dt, debug=0):
     out += ["\t.section\t.rodata,\"a\",@progbits", "\t.p2align\t6, 0x0", "\t.amdhsa_kernel %s" % name,
             "\t\t.amdhsa_group_segment_fixed_size %d" % LDS_BYTES,
             "\t\t.amdhsa_private_segment_fixed_size 0",
-            "\t\t.amdhsa_kernarg_size 56",
+            "\t\t.amdhsa_kernarg_size 64",
             "\t\t.amdhsa_user_sgpr_count 2",
             "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1",
             "\t\t.amdhsa_system_sgpr_workgroup_id_x 1",
@@ -688,7 +830,9 @@ def metadata(names):
                     "        .value_kind:     global_buffer"]
         for off in (48, 52):
             out += ["      - .offset:         %d" % off, "        .size:           4", "        .value_kind:     by_value"]
-        out += ["    .group_segment_fixed_size: %d" % LDS_BYTES, "    .kernarg_segment_align: 8", "    .kernarg_segment_size: 56",
+        out += ["      - .address_space:  global", "        .offset:         56", "        .size:           8",
+                "        .value_kind:     global_buffer"]
+        out += ["    .group_segment_fixed_size: %d" % LDS_BYTES, "    .kernarg_segment_align: 8", "    .kernarg_segment_size: 64",
                 "    .max_flat_workgroup_size: 256", "    .name:           %s" % name, "    .private_segment_fixed_size: 0",
                 "    .sgpr_count:     %d" % (NEXT_SGPR + 6), "    .sgpr_spill_count: 0", "    .symbol:         %s.kd" % name,
                 "    .uniform_work_group_size: 1", "    .uses_dynamic_stack: false", "    .vgpr_count:     %d" % (NEXT_VGPR + 256),

@@ -631,8 +631,42 @@ struct Tower72Args {
     void *y;
     const int32_t *rows, *nrows;
     int32_t batch, nblocks;
+    const int32_t *plan;
 };
-static_assert(sizeof(Tower72Args) == 56, "kernarg layout of hive_tower72_* (gen_tower_asm.py)");
+static_assert(sizeof(Tower72Args) == 64, "kernarg layout of hive_tower72_* (gen_tower_asm.py)");
+constexpr int kPlanMaxWg = 256, kPlanStride = 8;      // MAX_WG, PLAN_STRIDE / 4 of gen_tower_asm.py
+
+// The launch plan of a balanced tower: `grid` workgroups (one per CU, all resident) share pairs * nblocks block-steps evenly.
+// The pairs are laid end to end on a line of block-steps, workgroup c owns [c T, (c + 1) T) with T = ceil(steps / grid): a pair
+// cut by a boundary has its FIRST blocks (the later workgroup's share ... of the line, but run first thing there: "head") and
+// its last blocks (the earlier workgroup's share, run last there: "tail") on two workgroups; T >= nblocks guarantees the
+// head has finished long before the tail starts.  Entry = {head pair, head end block, first full pair, end of the full
+// pairs, tail pair, tail first block, 0, 0}; the hand-over flags (one int per pair) follow the kPlanMaxWg entries.
+__global__ void __launch_bounds__(256)
+tower72_plan_kernel(const int32_t *__restrict__ nrows, int batch, int nblocks, int grid, int32_t *__restrict__ plan, int maxpairs)
+{
+    const int c = threadIdx.x;
+    const int n = nrows ? *nrows : batch, pairs = (n + 1) / 2;
+    int32_t *flags = plan + kPlanMaxWg * kPlanStride;
+    for (int i = c; i < maxpairs; i += 256) flags[i] = 0;
+    int e[8] = {-1, 0, 0, 0, -1, 0, 0, 0};
+    if (c < grid) {
+        if (pairs <= grid) {
+            if (c < pairs) { e[2] = c; e[3] = c + 1; }
+        } else {
+            const long long steps = (long long)pairs * nblocks, T = (steps + grid - 1) / grid;
+            const long long v0 = c * T, v1 = v0 + T < steps ? v0 + T : steps;
+            if (v0 < v1) {
+                const int p0 = (int)(v0 / nblocks), o0 = (int)(v0 % nblocks), p1 = (int)(v1 / nblocks), o1 = (int)(v1 % nblocks);
+                e[2] = o0 ? p0 + 1 : p0;
+                e[3] = p1;
+                if (o0) { e[4] = p0; e[5] = o0; }
+                if (o1) { e[0] = p1; e[1] = o1; }
+            }
+        }
+    }
+    for (int k = 0; k < 8; ++k) plan[c * kPlanStride + k] = e[k];
+}
 
 struct Tower72Module {
     hipModule_t mod = nullptr;
@@ -703,8 +737,30 @@ extern "C" int hive_nn_compact_rows(const int8_t *need, int batch, int32_t *rows
     return HIVE_OK;
 }
 
+extern "C" long long hive_nn_tower72_plan_bytes(int batch)
+{
+    return (long long)(kPlanMaxWg * kPlanStride + (batch + 1) / 2 + 64) * 4;
+}
+
+static int tower72_launch(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
+                          const int32_t *rows, const int32_t *nrows, int32_t *plan, void *stream);
+
 extern "C" int hive_nn_tower72(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
                                const int32_t *rows, const int32_t *nrows, void *stream)
+{
+    return tower72_launch(x, w, bias, y, batch, nblocks, dtype, rows, nrows, nullptr, stream);
+}
+
+extern "C" int hive_nn_tower72_balanced(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
+                                        const int32_t *rows, const int32_t *nrows, void *plan_workspace, void *stream)
+{
+    if (!plan_workspace || ((uintptr_t)plan_workspace & 31))
+        return set_error(HIVE_E_ARG, "hive_nn_tower72_balanced: plan_workspace (hive_nn_tower72_plan_bytes, 32-byte aligned) is missing");
+    return tower72_launch(x, w, bias, y, batch, nblocks, dtype, rows, nrows, (int32_t *)plan_workspace, stream);
+}
+
+static int tower72_launch(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
+                          const int32_t *rows, const int32_t *nrows, int32_t *plan, void *stream)
 {
     if (!x || !w || !bias || !y || batch <= 0 || nblocks <= 0 || x == y)
         return set_error(HIVE_E_ARG, "hive_nn_tower72: bad argument (y must not alias x)");
@@ -714,10 +770,25 @@ extern "C" int hive_nn_tower72(const void *x, const void *w, const float *bias, 
     hipFunction_t fn = nullptr;
     int rc = tower72_function(dtype, &fn);
     if (rc != HIVE_OK) return rc;
-    Tower72Args args{x, w, bias, y, rows, nrows, batch, nblocks};
+    unsigned grid = (unsigned)((batch + 1) / 2);
+    if (plan) {
+        // one workgroup per CU, all resident at once (157 KB of LDS each): the grid is the chip, the plan deals the work
+        static int cus[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && cus[dev] == 0) {
+            hipDeviceProp_t prop;
+            cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : kPlanMaxWg;
+        }
+        const int chip = dev >= 0 && dev < 64 && cus[dev] > 0 ? (cus[dev] < kPlanMaxWg ? cus[dev] : kPlanMaxWg) : kPlanMaxWg;
+        if ((int)grid > chip) grid = (unsigned)chip;
+        hipLaunchKernelGGL(tower72_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nrows, batch, nblocks, (int)grid, plan,
+                           (batch + 1) / 2);
+    }
+    Tower72Args args{x, w, bias, y, rows, nrows, batch, nblocks, plan};
     size_t size = sizeof(args);
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-    hipError_t e = hipModuleLaunchKernel(fn, (unsigned)((batch + 1) / 2), 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, config);
+    hipError_t e = hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, config);
     if (e != hipSuccess) return set_error(HIVE_E_DEVICE, std::string("hive_nn_tower72: ") + hipGetErrorString(e));
     return HIVE_OK;
 }

@@ -82,6 +82,18 @@ int hive_nn_tower(const void *x, const void *w, const float *bias, void *y, int 
 int hive_nn_tower72(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
                     const int32_t *rows, const int32_t *nrows, void *stream);
 
+/* The same launch with its work BALANCED over the chip.  hive_nn_tower72 gives every pair of boards one workgroup for the
+ * whole tower, so its time is ceil(pairs / CUs) whole towers: 460 pairs on 256 CUs cost as much as 512.  Here one workgroup
+ * per CU runs; a plan kernel (same stream, reads *nrows on the device) lays the pairs' blocks end to end and gives every
+ * workgroup an equal share: a pair cut by a share boundary is started by one workgroup and finished by its neighbour, handed
+ * over through y (the blocks' outputs already live there) and an agent-scope release / acquire flag.  Time is proportional to
+ * the boards evaluated; results are the same bits.  plan_workspace: hive_nn_tower72_plan_bytes(batch) bytes, 32-byte
+ * aligned, contents undefined between calls.  Do not run two balanced launches concurrently on one device (each wants
+ * every CU; a tail that waits for a head that is not scheduled falls back to computing the pair itself after a bounded spin). */
+int hive_nn_tower72_balanced(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
+                             const int32_t *rows, const int32_t *nrows, void *plan_workspace, void *stream);
+long long hive_nn_tower72_plan_bytes(int batch);
+
 /* need int8[batch] (1 = evaluate) -> rows int32[batch] (indices of the flagged boards, ascending), *nrows = their number. */
 int hive_nn_compact_rows(const int8_t *need, int batch, int32_t *rows, int32_t *nrows, void *stream);
 

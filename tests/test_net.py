@@ -788,6 +788,27 @@ def test_hip_tower72_matches_resblock_chain(dtype):
             assert torch.equal(y[sel], want[sel]) and bool((y[~sel] == 7.0).all()), (B, nblk)
         else:
             assert torch.equal(y, want), (B, nblk, int((y != want).sum()))
+    # the balanced launch (one workgroup per CU, the pairs' blocks dealt evenly: pairs cut at a share boundary are handed
+    # from one workgroup to the next through y and a release / acquire flag): same bits, with and without a row list,
+    # fewer pairs than CUs, more pairs than CUs with every kind of remainder
+    for B, nblk, use_rows in ((7, 2, False), (300, 19, True), (700, 19, False), (1024, 19, True), (1031, 3, False), (2500, 5, True)):
+        x = torch.relu(torch.randn((B, 144, 256), device="cuda", generator=gen)).to(dtype)
+        w = (torch.randn((2 * nblk, 9 * 8 * 16 * 64 * 8), device="cuda", generator=gen) * 0.015).to(dtype)
+        bias = torch.randn((2 * nblk, 256), device="cuda", generator=gen) * 0.1
+        rows = nrows = need = None
+        if use_rows:
+            need = (torch.rand((B,), device="cuda", generator=gen) < 0.9).to(torch.int8)
+            rows = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+            nrows = torch.zeros((1,), dtype=torch.int32, device="cuda")
+            _lib.check(L.hive_nn_compact_rows(P(need), B, P(rows), P(nrows), st()))
+        want = torch.full_like(x, 7.0)
+        _lib.check(L.hive_nn_tower72(P(x), P(w), P(bias), P(want), B, nblk, DT, P(rows), P(nrows), st()))      # (checked against the chain above)
+        y = torch.full_like(x, 7.0)
+        ws = torch.empty((int(L.hive_nn_tower72_plan_bytes(B)),), dtype=torch.uint8, device="cuda")
+        for _ in range(2):                                            # (the plan and its flags are rebuilt by every launch)
+            _lib.check(L.hive_nn_tower72_balanced(P(x), P(w), P(bias), P(y), B, nblk, DT, P(rows), P(nrows), P(ws), st()))
+            torch.cuda.synchronize()
+            assert torch.equal(y, want), (B, nblk, use_rows, int((y != want).sum()))
     # arguments: rows without a count, aliased output
     assert L.hive_nn_tower72(P(x), P(w), P(bias), P(y), B, nblk, DT, P(y), None, st()) != 0
     assert L.hive_nn_tower72(P(x), P(w), P(bias), P(x), B, nblk, DT, None, None, st()) != 0
@@ -826,7 +847,7 @@ def test_inference_net_tower_forms_give_the_same_bits(dtype):
             assert torch.equal(pa, pb) and torch.equal(va, vb), rows
     # the default ("auto") takes the 72-tile assembly tower for batches that fill its rounds: same bits as the chain
     auto = InferenceNet(net, dtype=dtype, tune_gemms=False)
-    assert auto._tower_form(1024) == 72 and auto._tower_form(960) == 72 and auto._tower_form(640) == 0 and auto._tower_form(37) == 0
+    assert auto._tower_form(1024) == 72 and auto._tower_form(640) == 72 and auto._tower_form(400) == 0 and auto._tower_form(37) == 0
     xb = (torch.rand((1000, 12, 12, 56), device="cuda") < 0.08).to(dtype)
     pa, va = one(xb)
     for _ in range(2):

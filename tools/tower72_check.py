@@ -27,7 +27,10 @@ def chain(x, w, bias, nblk, dtype):
 
 ok = True
 for dtype in (torch.bfloat16, torch.float16):
-    for B, nblk, use_rows in ((2, 1, False), (5, 1, False), (64, 1, False), (7, 2, False), (64, 3, True), (300, MAXB, False), (1024, MAXB, True)):
+    for B, nblk, use_rows, balanced in ((2, 1, False, False), (5, 1, False, False), (64, 1, False, False), (7, 2, False, False),
+                                        (64, 3, True, False), (300, MAXB, False, False), (1024, MAXB, True, False),
+                                        (7, 2, False, True), (300, MAXB, True, True), (700, MAXB, False, True), (1024, MAXB, True, True),
+                                        (1031, 3, False, True), (2500, 5, True, True)):
         nblk = min(nblk, MAXB)
         x = torch.relu(torch.randn((B, 144, 256), device="cuda")).to(dtype)
         w = (torch.randn((2 * nblk, 9 * 8 * 16 * 64 * 8), device="cuda") * 0.015).to(dtype)
@@ -42,7 +45,11 @@ for dtype in (torch.bfloat16, torch.float16):
             _lib.check(L.hive_nn_compact_rows(P(need), B, P(rows), P(nrows), st()))
             k = int(nrows.item())
             assert k == int(need.sum().item()) and torch.equal(rows[:k].long(), torch.nonzero(need).flatten())
-        _lib.check(L.hive_nn_tower72(P(x), P(w), P(bias), P(y), B, nblk, DT[dtype], P(rows), P(nrows), st()))
+        if balanced:
+            ws = torch.empty((int(L.hive_nn_tower72_plan_bytes(B)),), dtype=torch.uint8, device="cuda")
+            _lib.check(L.hive_nn_tower72_balanced(P(x), P(w), P(bias), P(y), B, nblk, DT[dtype], P(rows), P(nrows), P(ws), st()))
+        else:
+            _lib.check(L.hive_nn_tower72(P(x), P(w), P(bias), P(y), B, nblk, DT[dtype], P(rows), P(nrows), st()))
         torch.cuda.synchronize()
         if use_rows:
             sel = need.bool()
@@ -51,7 +58,7 @@ for dtype in (torch.bfloat16, torch.float16):
             same = torch.equal(y, want)
         bad = (y != want).any(dim=2).any(dim=1) if not use_rows else ((y != want).any(dim=2).any(dim=1) & need.bool())
         md = float((y.float() - want.float()).abs().max())
-        print(f"{str(dtype):16s} B={B:5d} blocks={nblk:2d} rows={use_rows!s:5s}: {'identical' if same else 'DIFFERENT'}"
+        print(f"{str(dtype):16s} B={B:5d} blocks={nblk:2d} rows={use_rows!s:5s} balanced={balanced!s:5s}: {'identical' if same else 'DIFFERENT'}"
               f"  (boards differing: {int(bad.sum())}, max |d| {md:.4g}, finite {bool(torch.isfinite(y.float()).all())})", flush=True)
         if not same:
             ok = False

@@ -81,9 +81,24 @@ for dtype in (torch.bfloat16, torch.float16):
         forms["tower 1 board/wg" + sfx] = tower(lib, 1)
         forms["tower 2 boards/wg 8 waves" + sfx] = tower(lib, 2)
         forms["tower 1 board/wg 1 wave/SIMD" + sfx] = tower(lib, 3)
+    def tower72_balanced(lib, frac):
+        need = (torch.arange(B, device="cuda") < int(B * frac)).to(torch.int8)
+        rows = torch.empty((B,), dtype=torch.int32, device="cuda")
+        nrows = torch.empty((1,), dtype=torch.int32, device="cuda")
+        ws = torch.empty((int(lib.hive_nn_tower72_plan_bytes(B)),), dtype=torch.uint8, device="cuda")
+        assert lib.hive_nn_compact_rows(P(need), B, P(rows), P(nrows), st()) == 0
+        def run(y):
+            assert lib.hive_nn_tower72_balanced(P(x), P(w), P(bias), P(y[0]), B, NBLK, DT[dtype], P(rows), P(nrows), P(ws), st()) == 0
+            return y[0]
+        return run
+
     if hasattr(L, "hive_nn_tower72"):
         forms["tower72 asm (2 boards/wg, 72 tiles/wave)"] = tower72(L)
         forms["tower72 asm, launch per block"] = tower72_chain(L)
+        forms["tower72 balanced, every board"] = tower72_balanced(L, 1.0)
+        forms["tower72 balanced, 90 % of the boards"] = tower72_balanced(L, 0.9)
+        forms["tower72 balanced, 75 % of the boards"] = tower72_balanced(L, 0.75)
+        forms["tower72 balanced, 60 % of the boards"] = tower72_balanced(L, 0.6)
     outs, times = {}, {k: [] for k in forms}
     ys = {k: [torch.zeros_like(x), torch.zeros_like(x)] for k in forms}
     for k, f in forms.items():
@@ -104,6 +119,7 @@ for dtype in (torch.bfloat16, torch.float16):
           f"mean |y| {outs[first].float().abs().mean().item():.3f})")
     for k in forms:
         med, mn = statistics.median(times[k]), min(times[k])
-        same = "" if k == first else f"  identical to '{first}': {bool(torch.equal(outs[k], outs[first]))}"
+        nsel = int(B * float(k.split(",")[1].split("%")[0]) / 100) if "% of the boards" in k else B
+        same = "" if k == first else f"  identical to '{first}': {bool(torch.equal(outs[k][:nsel], outs[first][:nsel]))}"
         print(f"{k:34s} median {med:7.3f} ms ({flop / med / 1e9:5.0f} TFLOP/s, {med / NBLK * 1e3:6.1f} us per block)  min {mn:7.3f} ms{same}",
               flush=True)
