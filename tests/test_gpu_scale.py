@@ -592,7 +592,7 @@ def _replay_game_through_the_oracle(value_white, plies, gid):
 
 def test_finished_selfplay_games_replay_through_the_oracle(bf16_net):
     """The whole producer chain -- noisy search, move resampling on turns 1..6, env step, per-ply records, scoring -- for
-    128 games played to their end (8 simulations per move, bf16 network), judged by the CPU oracle instead of by the GPU's
+    512 games played to their end (50 simulations per move, the default fp16 engine), judged by the CPU oracle instead of by the GPU's
     own legal mask: the moves are recovered from consecutive recorded planes on oracle_py.OracleGame (the action after
     which the next recorded planes appear), so every played move is in the ORACLE's legal set, every recorded plane
     tensor equals the oracle's encode_board of that position, a side with an empty recorded policy really had no move,
@@ -600,12 +600,14 @@ def test_finished_selfplay_games_replay_through_the_oracle(bf16_net):
     value and [game_len, counter] fields are consistent (woker/self_play.py:116-193)."""
     from oracle import oracle_py as O
     from hive_alphazero_amd import mcts, records
-    G, sims = int(os.environ.get("HIVE_SOAK_GAMES", "128")), int(os.environ.get("HIVE_SOAK_SIMS", "8"))      # (soak runs: more of both)
+    # half of BASELINE configs[2] at its 50 simulations by default (512 games: the leaf batches run on the balanced 72-tile
+    # tower with row lists); HIVE_SOAK_GAMES=1024 is the full size
+    G, sims = int(os.environ.get("HIVE_SOAK_GAMES", "512")), int(os.environ.get("HIVE_SOAK_SIMS", "50"))
     slots = int(os.environ.get("HIVE_SOAK_SLOTS", "1"))             # leaves in flight per tree (virtual loss; BASELINE configs[4]: 4)
-    if os.environ.get("HIVE_SOAK_DTYPE") == "fp16":                 # the fp16 leaf evaluator through the same chain
+    if os.environ.get("HIVE_SOAK_DTYPE", "auto") != "bf16":         # the default engine (fp16 by the range probe) through the chain
         from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
         torch.manual_seed(0)
-        bf16_net = InferenceNet(ChessNet().cuda().eval(), dtype=torch.float16)
+        bf16_net = InferenceNet(ChessNet().cuda().eval())
     sp = mcts.SelfPlay(G, sims, bf16_net, seed=21, keep_records=True, game_ids=range(G), max_finished_kept=2 * G, slots=slots)
     games = []
     for _ in range(60):

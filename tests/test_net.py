@@ -614,13 +614,17 @@ def test_chessnet_matches_reference_wide_cpu_fp32(tag):
 # absolute logit error -- by 30, so its log-probability bounds are ~30 x those of the seeded init.
 # Measured on MI355X (round 3): init  fp16 0.0034 / 6.5e-7 / 1 / 1 / 7e-4      bf16 0.025 / 2.9e-5 / 0.97 / 0.97 / 5.5e-3
 #                              peak  fp16 0.052  / 9.7e-4 / 1 / 1 / 1.4e-3    bf16 0.47  / 0.046  / 0.98 / 0.95 / 0.031
+# (max |d log p| over the legal moves, max KL, top-1 agreement, top-5 agreement, max |dv|) per engine: <= 1.3x the values
+# measured in round 4 (hand-written heads: fp32 logits) -- init: fp16 0.00341 / 6.7e-7 / 1 / 1 / 7.5e-4, bf16 0.0248 / 2.6e-5 /
+# 0.984 / 0.969 / 5.6e-3; peak: fp16 0.127 / 4.9e-4 / 1 / 1 / 1.4e-3, bf16 0.817 / 0.0222 / 0.984 / 0.969 / 0.0309.  The kernels are
+# deterministic, so these are the numbers every box produces; the agreement floors leave room for one more of the 64 positions.
 WIDE_BOUNDS = {
     "init": {("float32", "torch"): (5e-4, 1e-6, 1.0, 1.0, 1e-4),
-             ("float16", "hip"): (1e-2, 5e-6, 0.95, 0.9, 3e-3),
-             ("bfloat16", "hip"): (6e-2, 2e-4, 0.9, 0.85, 2e-2)},
+             ("float16", "hip"): (4.5e-3, 9e-7, 0.98, 0.98, 1e-3),
+             ("bfloat16", "hip"): (3.3e-2, 3.5e-5, 0.95, 0.93, 7.3e-3)},
     "peak": {("float32", "torch"): (2e-3, 1e-6, 1.0, 1.0, 1e-4),
-             ("float16", "hip"): (0.15, 5e-3, 0.95, 0.9, 1e-2),
-             ("bfloat16", "hip"): (1.0, 0.1, 0.9, 0.8, 6e-2)},
+             ("float16", "hip"): (0.17, 6.5e-4, 0.98, 0.98, 1.8e-3),
+             ("bfloat16", "hip"): (1.06, 2.9e-2, 0.95, 0.93, 4.0e-2)},
 }
 
 
