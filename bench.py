@@ -193,6 +193,12 @@ def selfplay_measure(args, rank, local_rank, world):
                    "results": {"white": sp.white_wins, "black": sp.black_wins, "draw_or_cap": sp.draws},
                    "leaf_batch": {"skip_unread_rows": sp.search.skip_unread_rows, "share_equal_leaves": sp.search.share_equal_leaves}}
             leg.update(_leaf_accounting(sp.leaf_histogram(), launched, executed, el))
+            if sp.search._store is not None:
+                # rows answered from evaluations kept across plies: counted apart, never inside `achieved` (the roofline
+                # above divides the FLOPs of the rows the tower really evaluated by the wall time)
+                served, stored = sp.search.rows_served()
+                leg["leaf_rows_served_from_store"] = served
+                leg["leaf_rows_stored"] = stored
             sp.close()
             return leg
 
@@ -204,6 +210,13 @@ def selfplay_measure(args, rank, local_rank, world):
             out["whole_games_every_row_evaluated"] = {k: every[k] for k in ("games", "wall_s", "games_per_min", "ms_per_ply", "results",
                                                                            "leaf_batch", "leaf_rows_launched", "leaf_evals_executed",
                                                                            "roofline")}
+        if args.reuse:
+            # the same games with evaluations kept ACROSS plies (the reference empties its tree on every move, solo_play.py:103-112);
+            # identical search bit for bit (tests/test_gpu_search.py); off by default in the engine
+            reuse = whole_games_leg({"reuse_store": 1 << 17})
+            out["whole_games_with_reuse"] = {k: reuse[k] for k in ("games", "wall_s", "games_per_min", "ms_per_ply", "results",
+                                                                   "leaf_rows_launched", "leaf_evals_executed",
+                                                                   "leaf_rows_served_from_store", "leaf_rows_stored", "roofline")}
         out["whole_games"] = whole
         out["whole_games_" + dname] = {k: whole[k] for k in ("games", "wall_s", "games_per_min", "ms_per_ply", "results", "roofline")}
         out["games_per_min"] = whole["games_per_min"]
@@ -538,6 +551,8 @@ def main():
                     "the multi-rank path on a single GPU")
     ap.add_argument("--net-dtype", default="auto", choices=["auto", "bf16", "fp16"],
                     help="leaf-evaluator precision of the self-play legs (auto: fp16 if InferenceNet's range probe passes, else bf16)")
+    ap.add_argument("--no-reuse", dest="reuse", action="store_false",
+                    help="skip the whole-games leg that keeps leaf evaluations across plies (hive_leaf_store_*)")
     ap.add_argument("--no-both-dtypes", dest="both_dtypes", action="store_false",
                     help="skip the whole-games leg at the other 16-bit precision")
     ap.add_argument("--no-every-row", dest="every_row", action="store_false",

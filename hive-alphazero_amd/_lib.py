@@ -32,6 +32,8 @@ ABI_SYMBOLS = [
     "hive_batch_export", "hive_batch_import", "hive_movegen_launch", "hive_encode_launch",
     "hive_terminal_launch", "hive_step_launch", "hive_step_launch_counted", "hive_leaf_launch", "hive_expand_launch", "hive_leaf_dedup_launch",
     "hive_single_create", "hive_single_destroy", "hive_single_advance", "hive_single_encode",
+    "hive_leaf_store_create", "hive_leaf_store_destroy", "hive_leaf_store_clear", "hive_leaf_store_lookup", "hive_leaf_store_update",
+    "hive_leaf_store_stats",
     # include/hive_search.h
     "hive_search_create", "hive_search_destroy", "hive_search_set_stream", "hive_search_set_params",
     "hive_search_set_roots", "hive_search_select", "hive_search_backup", "hive_search_policy",
@@ -138,6 +140,12 @@ def load():
     L.hive_nn_heads_workspace_bytes.restype = ctypes.c_longlong
     L.hive_nn_heads_splits.argtypes = [i32]
     L.hive_leaf_dedup_launch.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
+    L.hive_leaf_store_create.argtypes = [i32, i32, ctypes.POINTER(vp)]
+    L.hive_leaf_store_destroy.argtypes = [vp]
+    L.hive_leaf_store_clear.argtypes = [vp, vp]
+    L.hive_leaf_store_lookup.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.hive_leaf_store_update.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.hive_leaf_store_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     f32, i64 = ctypes.c_float, ctypes.c_longlong
     L.hive_nn_bn_workspace_floats.restype = i32
     L.hive_nn_bn_act_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i64, i32, i32, vp]

@@ -435,6 +435,7 @@ class InferenceNet:
         for name, value in self._folded(net.eval()).items():
             setattr(self, name, value)
         self._graphs = {}
+        self.weights_version = 0
         self._tunable_before = None        # TunableOp's process-wide switch as it was before this object turned it on
         import threading
         self._lock = threading.Lock()      # capture/replay share static buffers: one caller at a time
@@ -569,6 +570,7 @@ class InferenceNet:
                 for d, s_ in zip(dst, src):
                     copy_into(d, s_)
         with self._lock, torch.no_grad():
+            self.weights_version += 1          # (consumers that keep evaluations -- mcts.TreeSearch(reuse_store=...) -- drop them)
             for name, value in self._folded(net).items():
                 copy_into(getattr(self, name), value)
             torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
@@ -756,6 +758,12 @@ class InferenceNet:
             torch.cuda.synchronize(self.device)
         finally:
             tn.tuning_enable(False)
+
+    @property
+    def batch_independent_bits(self):
+        """A position's (p, v) are the same bits in any batch at any row: every tower form is bit-identical and hive_nn_heads
+        sums over a fixed K split (the library heads' results depended on the row position in the last ulp)."""
+        return self.conv == "hip" and self.hip_heads
 
     @property
     def graph_batches(self):

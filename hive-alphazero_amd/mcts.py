@@ -37,7 +37,7 @@ class TreeSearch:
 
     def __init__(self, games, sims, evaluator, device=None, slots=1, seed=0, plane_dtype=None,
                  c_puct=0.7, noise_eps=0.25, dirichlet_alpha=0.3, max_nodes=None, transpositions=True, mode=PUCT,
-                 virtual_loss=None, max_game_length=None, skip_unread_rows=True, share_equal_leaves=True):
+                 virtual_loss=None, max_game_length=None, skip_unread_rows=True, share_equal_leaves=True, reuse_store=0):
         """mode = PUCT: woker/solo_play.py::HivePlayer; mode = UCT: alpha_zero/MCTS_chess.py::UCT_search (plain tree, no
         noise, no length cap; with one slot the virtual loss is 0 so that W sums exactly like the sequential reference)."""
         L = load()
@@ -97,11 +97,31 @@ class TreeSearch:
                           "are evaluated separately (share_equal_leaves off)")
         self.leaf_rep = torch.arange(n, dtype=torch.int32, device=dev)
         self.leaf_keys = torch.zeros((n,), dtype=torch.int64, device=dev)
+        # evaluations kept ACROSS searches (hive_leaf_store_*, include/hive_abi.h): the reference empties its tree on every
+        # move (solo_play.py:103-112) and evaluates the subtree under the played move again; reuse_store = entries (0 = off,
+        # the default).  Needs the equal-leaf keys; the served rows are counted apart from the evaluated ones (rows_served).
+        self._store = None
+        self._store_version = getattr(evaluator, "weights_version", 0)
+        if reuse_store and self.share_equal_leaves and getattr(evaluator, "batch_independent_bits", False):
+            self._store = ctypes.c_void_p()
+            check(L.hive_leaf_store_create(self.device.index, int(reuse_store), ctypes.byref(self._store)))
+            self.leaf_hit = torch.full((n,), -1, dtype=torch.int32, device=dev)
 
     def close(self):
         if getattr(self, "_h", None):
             self.L.hive_search_destroy(self._h)
             self._h = None
+        if getattr(self, "_store", None):
+            self.L.hive_leaf_store_destroy(self._store)
+            self._store = None
+
+    def rows_served(self):
+        """(rows answered from the store, rows inserted into it) since it was created or cleared."""
+        if self._store is None:
+            return 0, 0
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        check(self.L.hive_leaf_store_stats(self._store, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
 
     def __del__(self):
         try:
@@ -137,7 +157,18 @@ class TreeSearch:
                 if self.share_equal_leaves:
                     check(L.hive_leaf_dedup_launch(_p(self.leaf_boards), _p(self.leaf_hist), n, _p(self.leaf_need),
                                                    _p(self.leaf_rep), _p(self.leaf_keys), _p(self.evals_run), s))
+                    if self._store is not None:
+                        if getattr(self.evaluator, "weights_version", 0) != self._store_version:      # new weights: old answers are void
+                            check(L.hive_leaf_store_clear(self._store, s))
+                            self._store_version = getattr(self.evaluator, "weights_version", 0)
+                        check(L.hive_leaf_store_lookup(self._store, _p(self.leaf_boards), _p(self.leaf_hist), n, _p(self.leaf_keys),
+                                                       _p(self.leaf_need), _p(self.leaf_hit), _p(self.evals_run), s))
                     p, v = self.evaluator(self.planes[:n], need=self.leaf_need[:n], rep=self.leaf_rep[:n])
+                    if self._store is not None:
+                        p = p.float().contiguous()
+                        v = v.float().contiguous().view(-1)
+                        check(L.hive_leaf_store_update(self._store, _p(self.leaf_boards), _p(self.leaf_hist), n, _p(self.leaf_keys),
+                                                       _p(self.leaf_need), _p(self.leaf_rep), _p(self.leaf_hit), _p(p), _p(v), s))
                 else:
                     p, v = self.evaluator(self.planes[:n], need=self.leaf_need[:n])
             else:

@@ -180,6 +180,27 @@ int hive_leaf_launch(const HiveBoard *boards, const HiveHistory *hist, int n, vo
 int hive_leaf_dedup_launch(const HiveBoard *boards, const HiveHistory *hist, int n, int8_t *need, int32_t *rep,
                            uint64_t *keys, uint64_t *total, void *stream);
 
+/* ---- A store of leaf evaluations that outlives a search.  The reference empties its tree on every move
+ * (woker/solo_play.py:103-112), so the positions under the move just played -- and the openings of every later game -- are
+ * evaluated again; a leaf's (p, v) is a pure function of its HiveBoard + HiveHistory, and this engine produces the same
+ * bits for a position in any batch at any row, so a stored evaluation can stand in for a fresh one without changing the
+ * search.  `capacity` entries (448 bytes of key material + 1585 floats each) in a ring: the oldest are overwritten.
+ *   lookup  (after hive_leaf_dedup_launch, whose `keys` it takes): rows still flagged in need[] whose position is stored --
+ *           64-bit key, then all 448 bytes compared -- are switched off; hit[row] = the slot, else -1; the number of rows
+ *           switched off is subtracted from *total (may be NULL)
+ *   update  (after the forward): row i takes (p, v) of slot hit[rep[i]] if that is >= 0 (rep may be NULL: identity); every
+ *           row that was evaluated (need[i] still 1) is inserted.  p f32 [n][1584], v f32 [n] are the evaluator's outputs.
+ * Clear the store whenever the network's weights change.  Not thread-safe; one stream at a time. */
+typedef struct HiveLeafStore HiveLeafStore;
+int hive_leaf_store_create(int device, int capacity, HiveLeafStore **out);
+int hive_leaf_store_destroy(HiveLeafStore *s);
+int hive_leaf_store_clear(HiveLeafStore *s, void *stream);
+int hive_leaf_store_lookup(HiveLeafStore *s, const HiveBoard *boards, const HiveHistory *hist, int n, const uint64_t *keys,
+                           int8_t *need, int32_t *hit, uint64_t *total, void *stream);
+int hive_leaf_store_update(HiveLeafStore *s, const HiveBoard *boards, const HiveHistory *hist, int n, const uint64_t *keys,
+                           const int8_t *need, const int32_t *rep, const int32_t *hit, float *p, float *v, void *stream);
+int hive_leaf_store_stats(HiveLeafStore *s, uint64_t *served, uint64_t *inserted);   /* synchronises */
+
 /* ---- One position, HOST buffers: the single-game surface of GamePlay without a round trip per question.
  * A HiveSingle owns a stream, a device block and a pinned host mirror; a call copies the position in, runs its kernels
  * as one launch chain, copies the answers out and synchronises once.  Not thread-safe; distinct handles are independent

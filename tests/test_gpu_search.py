@@ -570,3 +570,49 @@ def test_sharing_equal_leaves_does_not_change_the_search():
             assert out[True][3] < 0.7 * out[False][3]
     assert B.illegal_count() == 0
     B.close()
+
+
+@pytest.mark.gpu
+def test_reusing_stored_evaluations_does_not_change_the_search():
+    """TreeSearch(reuse_store=N) keeps (p, v) of evaluated leaves ACROSS searches (hive_leaf_store_*): the reference empties its
+    tree on every move (solo_play.py:103-112) and evaluates the positions under the played move again.  Two self-play engines
+    on the same 192 games, one with the store: every ply's actions, visit policies and visit totals must be identical bit for
+    bit -- a position's (p, v) do not depend on the batch or row it is evaluated in (hive_nn_heads, the bit-identical tower
+    forms) -- while from the second ply on rows are served from the store and fewer go through the tower.  New weights
+    (InferenceNet.refresh) void the store."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd import mcts
+    from hive_alphazero_amd.alpha_net import ChessNet, InferenceNet
+    torch.manual_seed(0)
+    net = ChessNet().cuda().eval()
+    inf = InferenceNet(net)
+    assert inf.batch_independent_bits
+    G, sims = 192, 24
+    plain = mcts.SelfPlay(G, sims, inf, seed=9, keep_records=False, game_ids=range(G))
+    kept = mcts.SelfPlay(G, sims, inf, seed=9, keep_records=False, game_ids=range(G), search_options={"reuse_store": 1 << 15})
+    assert kept.search._store is not None and plain.search._store is None
+    served_before = 0
+    for ply in range(5):
+        e0p, e0k = int(plain.search.evals_run.item()), int(kept.search.evals_run.item())
+        plain.play_ply()
+        kept.play_ply()
+        for a, b in ((plain.search.action, kept.search.action), (plain.search.policy, kept.search.policy),
+                     (plain.search.sum_n, kept.search.sum_n)):
+            assert torch.equal(a, b), ply
+        served, inserted = kept.search.rows_served()
+        ran_p, ran_k = int(plain.search.evals_run.item()) - e0p, int(kept.search.evals_run.item()) - e0k
+        print(f"ply {ply}: rows through the tower {ran_p} -> {ran_k}, served from the store {served - served_before}, stored so far {inserted}")
+        assert ran_k + (served - served_before) == ran_p          # every served row is a row the plain engine evaluated
+        if ply >= 1:
+            assert served > served_before and ran_k < ran_p
+        served_before = served
+    assert plain.env.illegal_count() == 0 and kept.env.illegal_count() == 0
+    # new weights: the stored answers are dropped, the searches still agree
+    torch.manual_seed(1)
+    inf.refresh(ChessNet().cuda().eval())
+    plain.play_ply()
+    kept.play_ply()
+    assert torch.equal(plain.search.action, kept.search.action) and torch.equal(plain.search.policy, kept.search.policy)
+    assert kept.search.rows_served()[0] < served_before + G * sims  # (the counters restarted with the cleared store)
+    plain.close()
+    kept.close()
