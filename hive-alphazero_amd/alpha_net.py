@@ -211,6 +211,7 @@ class _Conv3x3(torch.autograd.Function):
     hive_nn_pack_conv3x3_weights); the weight gradient of the 256 -> 256 convolutions is hive_nn_conv3x3_wgrad (pixels as
     the contraction dimension, transposing LDS reads); only the 56-channel stem's stays on the library (MIOpen) path."""
     hip_wgrad = True
+    asm_conv = True          # forward / data gradient of the 256 -> 256 convolutions on hive_nn_conv72
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -228,7 +229,10 @@ class _Conv3x3(torch.autograd.Function):
         _lib.check(L.hive_nn_pack_conv3x3_weights(p(wsrc), cin, 0, wcl, p(wp), st))
         b = bias if bias is not None else _const("zero_bias", 0, dev)
         y = torch.empty((B, 256, 12, 12), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
-        _lib.check(L.hive_nn_conv3x3(p(x), cin, p(wp), p(b), None, p(y), B, 0, st))
+        if cin == 256 and _Conv3x3.asm_conv:         # the 72-tile assembly kernel (two boards per workgroup): same bits
+            _lib.check(L.hive_nn_conv72(p(x), p(wp), p(b), p(y), B, 0, _lib.BF16, st))
+        else:
+            _lib.check(L.hive_nn_conv3x3(p(x), cin, p(wp), p(b), None, p(y), B, 0, st))
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y
@@ -250,7 +254,10 @@ class _Conv3x3(torch.autograd.Function):
             wsrc, wcl = _weight_layout(weight)
             _lib.check(L.hive_nn_pack_conv3x3_weights(p(wsrc), cin, 1, wcl, p(wt), st))
             dx = torch.empty_like(x)
-            _lib.check(L.hive_nn_conv3x3(p(dy), 256, p(wt), p(_const("zero_bias", 0, dev)), None, p(dx), B, 0, st))
+            if cin == 256 and _Conv3x3.asm_conv:
+                _lib.check(L.hive_nn_conv72(p(dy), p(wt), p(_const("zero_bias", 0, dev)), p(dx), B, 0, _lib.BF16, st))
+            else:
+                _lib.check(L.hive_nn_conv3x3(p(dy), 256, p(wt), p(_const("zero_bias", 0, dev)), None, p(dx), B, 0, st))
         if cin == 256 and _Conv3x3.hip_wgrad:
             taps = torch.empty((3, 3, 256, 256), dtype=torch.float32, device=dev)
             _lib.check(L.hive_nn_conv3x3_wgrad(p(x), p(dy), p(taps), B, p(_wgrad_workspace(L, dev)), st))

@@ -51,7 +51,8 @@ V_GO = V_SK + 32              # 4: global pixel offsets of the batches in flight
 V_LDSW = V_GO + 4             # 3: epilogue LDS write bases
 V_GOFF = V_LDSW + 3           # 1: lr * 512 + lg * 8 + wave * 128
 V_BIASOFF = V_GOFF + 1        # 1: wave * 256 + lg * 16
-V_TMP = V_BIASOFF + 1         # 4 scratch
+V_FLOOR = V_BIASOFF + 1       # 1: the epilogues' lower clamp: 0.0 (ReLU) or -inf (none)
+V_TMP = V_FLOOR + 1           # 4 scratch
 V_END = V_TMP + 4
 assert V_END <= 256, V_END
 NEXT_VGPR = (V_END + 7) // 8 * 8
@@ -81,6 +82,7 @@ S_D = 56                      # 8: this workgroup's plan entry: head pair, head 
                               #    pairs, tail pair, tail first block, -, -
 S_PHASE, S_PAIR, S_B0, S_B1, S_MODE, S_POLL = 64, 65, 66, 67, 68, 69
 S_FLAG = 70                   # pair: address of the current pair's hand-over flag
+S_FLAGS = 76                  # kernarg flags: bit 0 = ONE convolution per block (conv + bias [+ ReLU] -> y), bit 1 = no ReLU
 S_STG0, S_STG1 = 72, 74       # pairs: where the current segment's boards are staged from (X rows, or Y rows for a tail)
 PLAN_STRIDE = 32              # bytes per workgroup in the plan
 MAX_WG = 256                  # workgroups a plan covers; the flags start at plan + MAX_WG * PLAN_STRIDE
@@ -185,10 +187,11 @@ def gen_kernel(name, dt, debug=0):
     e, c = A.e, A.comment
 
     # =============================================================== prologue
-    c("kernarg: X W bias Y idx count | batch nblocks | plan")
+    c("kernarg: X W bias Y idx count | batch nblocks | plan | flags")
     e("s_load_dwordx8 %s, %s, 0x0" % (sr(S_X, 8), sr(S_KARG, 2)))
     e("s_load_dwordx4 %s, %s, 0x20" % (sr(S_IDX, 4), sr(S_KARG, 2)))
     e("s_load_dwordx4 %s, %s, 0x30" % (sr(S_N, 4), sr(S_KARG, 2)))
+    e("s_load_dword %s, %s, 0x40" % (sr(S_FLAGS), sr(S_KARG, 2)))
     e("v_lshrrev_b32_e32 %s, 6, %s" % (vr(V_TMP), vr(V_TID)))
     e("s_nop 1")                                 # (a VALU-written register is not yet visible to v_readfirstlane)
     e("v_readfirstlane_b32 %s, %s" % (sr(S_WAVE), vr(V_TMP)))
@@ -240,6 +243,9 @@ def gen_kernel(name, dt, debug=0):
     e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(V_BIASOFF), vr(LG)))
     e("v_add_u32_e32 %s, %s, %s" % (vr(V_BIASOFF), sr(S_T1), vr(V_BIASOFF)))
 
+    e("s_bitcmp1_b32 %s, 1" % sr(S_FLAGS))
+    e("s_cselect_b32 %s, 0xff800000, 0" % sr(S_T1))
+    e("v_mov_b32_e32 %s, %s" % (vr(V_FLOOR), sr(S_T1)))
     c("table of tap offsets (.rodata of this code object), biased by 2048 so that 18 rows fit the 13-bit offsets")
     e("s_getpc_b64 %s" % sr(S_TAB, 2))
     e("s_add_u32 %s, %s, hive_tap_table@rel32@lo+2052" % (sr(S_TAB), sr(S_TAB)))
@@ -371,6 +377,8 @@ def gen_kernel(name, dt, debug=0):
     e("s_sub_u32 %s, %s, %s" % (sr(S_WLEFT), sr(S_NBLK), sr(S_B0)))
     e("s_mul_i32 %s, %s, 144" % (sr(S_WLEFT), sr(S_WLEFT)))
     e("s_sub_u32 %s, %s, %d" % (sr(S_WLEFT), sr(S_WLEFT), AD + 1))
+    e("s_bitcmp1_b32 %s, 0" % sr(S_FLAGS))               # ONE convolution in all (b0 = 0, one block): its 72 k-steps
+    e("s_cselect_b32 %s, %d, %s" % (sr(S_WLEFT), 72 - AD - 1, sr(S_WLEFT)))
 
     c("stage both boards: 36 sixteen-byte loads per thread, all in flight, then 36 LDS writes")
     ST_ADDR, ST_G = V_BOFF, V_BOFF + 1          # (V_BOFF.. are dead until the first convolution)
@@ -588,6 +596,55 @@ def gen_kernel(name, dt, debug=0):
         e("s_lshl_b32 %s, %s, 7" % (sr(S_T1), sr(S_T1)))
         e("s_add_u32 52, %s, %s" % (sr(S_IDX), sr(S_T1)) if False else "s_add_u32 s52, %s, %s" % (sr(S_IDX), sr(S_T1)))
         e("s_addc_u32 s53, %s, 0" % sr(S_IDX + 1))
+    GROUPS = [V_BOFF + 4 * i for i in range((NT + NTP) // 4)] + [V_T + 4 * i for i in range((30 + 32) // 4)]
+    assert len(GROUPS) >= 18
+    ST_ADDR, ST_G = V_TMP + 2, V_TMP + 3
+
+    def st_regs():
+        e("v_lshrrev_b32_e32 %s, 5, %s" % (vr(ST_ADDR), vr(V_TID)))
+        e("v_mul_u32_u24_e32 %s, 0x%x, %s" % (vr(ST_ADDR), PS, vr(ST_ADDR)))
+        e("v_and_b32_e32 %s, 31, %s" % (vr(V_TMP), vr(V_TID)))
+        e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(V_TMP), vr(V_TMP)))
+        e("v_add_u32_e32 %s, %s, %s" % (vr(ST_ADDR), vr(ST_ADDR), vr(V_TMP)))
+        e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(ST_G), vr(V_TID)))
+
+    def image_addr(slot, j):
+        """(address register, immediate) of this thread's j-th 16-byte piece of board `slot` in the LDS image."""
+        cst = (8 * j + 144 * slot) * PS
+        hi, lo = cst // 32768 * 32768, cst % 32768
+        if hi:
+            e("v_add_u32_e32 %s, 0x%x, %s" % (vr(V_TMP + 1), hi, vr(ST_ADDR)))
+            return vr(V_TMP + 1), lo
+        return vr(ST_ADDR), lo
+
+    def image_to_y():
+        c("image -> Y, sixteen bytes per lane, 1 KiB per wave-instruction")
+        PIPE = 9
+        order = [(slot, j) for slot in (0, 1) for j in range(18)]
+
+        def out_read(i):
+            slot, j = order[i]
+            adr, lo = image_addr(slot, j)
+            A.lg("ds_read_b128 %s, %s offset:%d" % (vr(GROUPS[i % 18], 4), adr, lo), ("or", i))
+
+        for i in range(PIPE):
+            out_read(i)
+        for i, (slot, j) in enumerate(order):
+            if j == 0:
+                e("s_mov_b64 %s, %s" % (sr(S_SRC, 2), sr(S_Y1 if slot else S_Y0, 2)))
+                if slot:
+                    e("s_mov_b64 exec, %s" % sr(S_HAS1, 2))          # (a repeated tail board is stored once)
+            A.wait(lg_tag=("or", i))
+            A.vm("global_store_dwordx4 %s, %s, %s" % (vr(ST_G), vr(GROUPS[i % 18], 4), sr(S_SRC, 2)), ("st", i))
+            if j < 17:
+                e("s_add_u32 %s, %s, 0x1000" % (sr(S_SRC), sr(S_SRC)))
+                e("s_addc_u32 %s, %s, 0" % (sr(S_SRC + 1), sr(S_SRC + 1)))
+            if i + PIPE < len(order):
+                if i + PIPE >= 18:
+                    A.wait(vm_tag=("st", i + PIPE - 18))             # (the register group's previous store has read its data)
+                out_read(i + PIPE)
+        e("s_mov_b64 exec, -1")
+
     A.label(".L%s_block" % name)
     stamp(0)
     if debug == 2:
@@ -613,7 +670,7 @@ def gen_kernel(name, dt, debug=0):
             e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 4, 2), vr(src, 2), vr(V_BIAS + 4 * mt, 2)))
             e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 6, 2), vr(src + 2, 2), vr(V_BIAS + 4 * mt + 2, 2)))
             for i in range(4):
-                e("v_max_f32_e32 %s, 0, %s" % (vr(tmp + 4 + i), vr(tmp + 4 + i)))
+                e("v_max_f32_e32 %s, %s, %s" % (vr(tmp + 4 + i), vr(V_FLOOR), vr(tmp + 4 + i)))
             e("%s %s, %s, %s" % (cvt, vr(tmp + 8), vr(tmp + 4), vr(tmp + 5)))
             e("%s %s, %s, %s" % (cvt, vr(tmp + 9), vr(tmp + 6), vr(tmp + 7)))
             if len(A.lg_q) >= 3:
@@ -626,6 +683,14 @@ def gen_kernel(name, dt, debug=0):
     if debug == 3:
         c("DEBUG 3: the intermediate boards (relu(conv1 + b1)) back out, stop")
         return dump_lds_and_stop()
+    c("ONE convolution per block (kernarg flags bit 0): the image is the result -> y, next segment")
+    e("s_bitcmp1_b32 %s, 0" % sr(S_FLAGS))
+    e("s_cbranch_scc0 .L%s_twoconv" % name)
+    st_regs()
+    image_to_y()
+    A.drain(vm=False, lg=True)
+    e("s_branch .L%s_blockend" % name)
+    A.label(".L%s_twoconv" % name)
 
     # =============================================================== conv2 + epilogue 2
     conv("c2")
@@ -644,25 +709,7 @@ def gen_kernel(name, dt, debug=0):
     #   1. x (the block's input) -> LDS image, coalesced, like the prologue's staging (the intermediate boards are dead now)
     #   2. per accumulator tile: skip = the lane's own 8 bytes of the image; result written back to the same 8 bytes
     #   3. LDS image (= the next block's input) -> Y, coalesced; no barrier after it: the next convolution only reads LDS
-    GROUPS = [V_BOFF + 4 * i for i in range((NT + NTP) // 4)] + [V_T + 4 * i for i in range((30 + 32) // 4)]
-    assert len(GROUPS) >= 18
-    ST_ADDR, ST_G = V_TMP + 2, V_TMP + 3
-    e("v_lshrrev_b32_e32 %s, 5, %s" % (vr(ST_ADDR), vr(V_TID)))
-    e("v_mul_u32_u24_e32 %s, 0x%x, %s" % (vr(ST_ADDR), PS, vr(ST_ADDR)))
-    e("v_and_b32_e32 %s, 31, %s" % (vr(V_TMP), vr(V_TID)))
-    e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(V_TMP), vr(V_TMP)))
-    e("v_add_u32_e32 %s, %s, %s" % (vr(ST_ADDR), vr(ST_ADDR), vr(V_TMP)))
-    e("v_lshlrev_b32_e32 %s, 4, %s" % (vr(ST_G), vr(V_TID)))
-
-    def image_addr(slot, j):
-        """(address register, immediate) of this thread's j-th 16-byte piece of board `slot` in the LDS image."""
-        cst = (8 * j + 144 * slot) * PS
-        hi, lo = cst // 32768 * 32768, cst % 32768
-        if hi:
-            e("v_add_u32_e32 %s, 0x%x, %s" % (vr(V_TMP + 1), hi, vr(ST_ADDR)))
-            return vr(V_TMP + 1), lo
-        return vr(ST_ADDR), lo
-
+    st_regs()
     for slot, base in ((0, S_SKIP0), (1, S_SKIP1)):
         e("s_mov_b64 %s, %s" % (sr(S_SRC, 2), sr(base, 2)))
         for j in range(18):
@@ -718,7 +765,7 @@ def gen_kernel(name, dt, debug=0):
         e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 4, 2), vr(tmp + 4, 2), vr(tmp + 0, 2)))
         e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 6, 2), vr(tmp + 6, 2), vr(tmp + 2, 2)))
         for k4 in range(4):
-            e("v_max_f32_e32 %s, 0, %s" % (vr(tmp + 4 + k4), vr(tmp + 4 + k4)))
+            e("v_max_f32_e32 %s, %s, %s" % (vr(tmp + 4 + k4), vr(V_FLOOR), vr(tmp + 4 + k4)))
         e("%s %s, %s, %s" % (cvt, vr(tmp + 8), vr(tmp + 4), vr(tmp + 5)))
         e("%s %s, %s, %s" % (cvt, vr(tmp + 9), vr(tmp + 6), vr(tmp + 7)))
         A.lg("ds_write_b64 %s, %s offset:%d" % (vr(V_LDSW + nt // 7), vr(tmp + 8, 2), (nt % 7) * 16 * PS + mt * 32), ("w2", t))
@@ -727,32 +774,7 @@ def gen_kernel(name, dt, debug=0):
     e("s_barrier")                                   # the image holds the block's output = the next block's input
     if debug == 5:
         stamp(9)
-    c("image -> Y, sixteen bytes per lane, 1 KiB per wave-instruction")
-    PIPE = 9
-    order = [(slot, j) for slot in (0, 1) for j in range(18)]
-
-    def out_read(i):
-        slot, j = order[i]
-        adr, lo = image_addr(slot, j)
-        A.lg("ds_read_b128 %s, %s offset:%d" % (vr(GROUPS[i % 18], 4), adr, lo), ("or", i))
-
-    for i in range(PIPE):
-        out_read(i)
-    for i, (slot, j) in enumerate(order):
-        if j == 0:
-            e("s_mov_b64 %s, %s" % (sr(S_SRC, 2), sr(S_Y1 if slot else S_Y0, 2)))
-            if slot:
-                e("s_mov_b64 exec, %s" % sr(S_HAS1, 2))          # (a repeated tail board is stored once)
-        A.wait(lg_tag=("or", i))
-        A.vm("global_store_dwordx4 %s, %s, %s" % (vr(ST_G), vr(GROUPS[i % 18], 4), sr(S_SRC, 2)), ("st", i))
-        if j < 17:
-            e("s_add_u32 %s, %s, 0x1000" % (sr(S_SRC), sr(S_SRC)))
-            e("s_addc_u32 %s, %s, 0" % (sr(S_SRC + 1), sr(S_SRC + 1)))
-        if i + PIPE < len(order):
-            if i + PIPE >= 18:
-                A.wait(vm_tag=("st", i + PIPE - 18))             # (the register group's previous store has read its data)
-            out_read(i + PIPE)
-    e("s_mov_b64 exec, -1")
+    image_to_y()
     A.drain(vm=False, lg=True)
     if debug == 5:
         A.drain()
@@ -760,6 +782,7 @@ def gen_kernel(name, dt, debug=0):
     if debug == 5:
         e("s_add_u32 s52, s52, 128")
         e("s_addc_u32 s53, s53, 0")
+    A.label(".L%s_blockend" % name)
     c("next block: its skip operand is what was just stored")
     e("s_mov_b64 %s, %s" % (sr(S_SKIP0, 2), sr(S_Y0, 2)))
     e("s_mov_b64 %s, %s" % (sr(S_SKIP1, 2), sr(S_Y1, 2)))
@@ -800,7 +823,7 @@ def kernel_text(name, dt, debug=0):
     out += ["\t.section\t.rodata,\"a\",@progbits", "\t.p2align\t6, 0x0", "\t.amdhsa_kernel %s" % name,
             "\t\t.amdhsa_group_segment_fixed_size %d" % LDS_BYTES,
             "\t\t.amdhsa_private_segment_fixed_size 0",
-            "\t\t.amdhsa_kernarg_size 64",
+            "\t\t.amdhsa_kernarg_size 72",
             "\t\t.amdhsa_user_sgpr_count 2",
             "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1",
             "\t\t.amdhsa_system_sgpr_workgroup_id_x 1",
@@ -832,7 +855,8 @@ def metadata(names):
             out += ["      - .offset:         %d" % off, "        .size:           4", "        .value_kind:     by_value"]
         out += ["      - .address_space:  global", "        .offset:         56", "        .size:           8",
                 "        .value_kind:     global_buffer"]
-        out += ["    .group_segment_fixed_size: %d" % LDS_BYTES, "    .kernarg_segment_align: 8", "    .kernarg_segment_size: 64",
+        out += ["      - .offset:         64", "        .size:           4", "        .value_kind:     by_value"]
+        out += ["    .group_segment_fixed_size: %d" % LDS_BYTES, "    .kernarg_segment_align: 8", "    .kernarg_segment_size: 72",
                 "    .max_flat_workgroup_size: 256", "    .name:           %s" % name, "    .private_segment_fixed_size: 0",
                 "    .sgpr_count:     %d" % (NEXT_SGPR + 6), "    .sgpr_spill_count: 0", "    .symbol:         %s.kd" % name,
                 "    .uniform_work_group_size: 1", "    .uses_dynamic_stack: false", "    .vgpr_count:     %d" % (NEXT_VGPR + 256),

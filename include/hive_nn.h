@@ -94,6 +94,11 @@ int hive_nn_tower72_balanced(const void *x, const void *w, const float *bias, vo
                              const int32_t *rows, const int32_t *nrows, void *plan_workspace, void *stream);
 long long hive_nn_tower72_plan_bytes(int batch);
 
+/* ONE 256 -> 256 3x3 convolution on the same 72-tile kernel: y = [relu](conv(x, w) + bias), arguments as hive_nn_conv3x3_dt
+ * with cin = 256 and no residual (two boards per workgroup; bit-identical to it).  What the training step's forward and
+ * data-gradient convolutions run on (alpha_net.py:117-162 as executed by alpha_net.Trainer). */
+int hive_nn_conv72(const void *x, const void *w, const float *bias, void *y, int batch, int relu, int dtype, void *stream);
+
 /* need int8[batch] (1 = evaluate) -> rows int32[batch] (indices of the flagged boards, ascending), *nrows = their number. */
 int hive_nn_compact_rows(const int8_t *need, int batch, int32_t *rows, int32_t *nrows, void *stream);
 

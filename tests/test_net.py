@@ -813,6 +813,19 @@ def test_hip_tower72_matches_resblock_chain(dtype):
             _lib.check(L.hive_nn_tower72_balanced(P(x), P(w), P(bias), P(y), B, nblk, DT, P(rows), P(nrows), P(ws), st()))
             torch.cuda.synchronize()
             assert torch.equal(y, want), (B, nblk, use_rows, int((y != want).sum()))
+    # ONE convolution on the same kernel (hive_nn_conv72: what the training step's forward / data-gradient convolutions use)
+    # == hive_nn_conv3x3_dt, with and without ReLU, odd and even batches, negative outputs kept when there is no ReLU
+    for B in (1, 6, 513):
+        x = torch.randn((B, 144, 256), device="cuda", generator=gen).to(dtype)
+        w1 = (torch.randn((9 * 8 * 16 * 64 * 8,), device="cuda", generator=gen) * 0.015).to(dtype)
+        b1 = torch.randn((256,), device="cuda", generator=gen) * 0.1
+        for relu in (0, 1):
+            want, got = torch.full_like(x, 7.0), torch.full_like(x, 7.0)
+            _lib.check(L.hive_nn_conv3x3_dt(P(x), 256, P(w1), P(b1), None, P(want), B, relu, DT, st()))
+            _lib.check(L.hive_nn_conv72(P(x), P(w1), P(b1), P(got), B, relu, DT, st()))
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (B, relu, int((got != want).sum()))
+            assert relu or bool((got.float() < 0).any())
     # arguments: rows without a count, aliased output
     assert L.hive_nn_tower72(P(x), P(w), P(bias), P(y), B, nblk, DT, P(y), None, st()) != 0
     assert L.hive_nn_tower72(P(x), P(w), P(bias), P(x), B, nblk, DT, None, None, st()) != 0
