@@ -145,6 +145,7 @@ policy_fc_kernel(const typename E::T *__restrict__ a, const typename E::T *__res
                  int splits)
 {
     typedef typename E::v8 v8;
+    typedef typename E::T T;
     constexpr int KS = 4;                                           // k-steps per stage
     constexpr int STAGE_FRAGS = KS * kFcNB;                         // 44 fragments of 1 KiB per stage
     constexpr int LOADS = (STAGE_FRAGS * 64 + 511) / 512;           // 16-byte pieces per thread and stage (6, the last partial)
@@ -171,24 +172,37 @@ policy_fc_kernel(const typename E::T *__restrict__ a, const typename E::T *__res
     const int s0 = (int)((long long)nstages * zz / splits), s1 = (int)((long long)nstages * (zz + 1) / splits);
     const int m0 = mt0 < mtiles ? mt0 : mtiles - 1, m1 = mt0 + 1 < mtiles ? mt0 + 1 : mtiles - 1;   // tail tiles repeat the last one, never stored
 
-    // piece q of a stage: fragment q / 64 (= kk * 11 + n), lane q % 64
-    uint4 breg[LOADS];
-    auto load_b = [&](int st) {
+    // piece q of a stage: fragment q / 64 (= kk * 11 + n), lane q % 64; thread t moves pieces t, t + 512, ..., t + 2560 (the
+    // last one only for t < 256).  Explicit scalars, unconditional loads (the odd piece reads a clamped address): as an
+    // array filled under a condition hipcc parked these registers in LDS (48 KiB of "promoted alloca", every piece written
+    // and read back once more, and the wait for the loads moved in front of the stage's MFMAs).
+    static_assert(LOADS == 6 && STAGE_FRAGS * 64 == 5 * 512 + 256, "piece schedule of a stage");
+    const bool last_piece = tid < 256;
+    const T *bsrc[LOADS];
 #pragma unroll
-        for (int j = 0; j < LOADS; ++j) {
-            const int q = tid + j * 512;
-            if (q < STAGE_FRAGS * 64) {
-                const int f = q >> 6, kk = f / kFcNB, n = f - kk * kFcNB;
-                breg[j] = *reinterpret_cast<const uint4 *>(w + (((size_t)(nt0 + n) * kFcKsteps + st * KS + kk) * 64 + (q & 63)) * 8);
-            }
-        }
+    for (int j = 0; j < LOADS; ++j) {
+        const int q = j < 5 ? tid + j * 512 : (last_piece ? tid + 2560 : tid + 2048);
+        const int f = q >> 6, kk = f / kFcNB, n = f - kk * kFcNB;
+        bsrc[j] = w + (((size_t)(nt0 + n) * kFcKsteps + kk) * 64 + (q & 63)) * 8;       // + stage * KS * 512 elements
+    }
+    uint4 b0, b1, b2, b3, b4, b5;
+    auto load_b = [&](int st) {
+        const size_t o = (size_t)st * KS * 512;
+        b0 = *reinterpret_cast<const uint4 *>(bsrc[0] + o);
+        b1 = *reinterpret_cast<const uint4 *>(bsrc[1] + o);
+        b2 = *reinterpret_cast<const uint4 *>(bsrc[2] + o);
+        b3 = *reinterpret_cast<const uint4 *>(bsrc[3] + o);
+        b4 = *reinterpret_cast<const uint4 *>(bsrc[4] + o);
+        b5 = *reinterpret_cast<const uint4 *>(bsrc[5] + o);
     };
     auto store_b = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < LOADS; ++j) {
-            const int q = tid + j * 512;
-            if (q < STAGE_FRAGS * 64) *reinterpret_cast<uint4 *>(bl[buf] + (size_t)q * 16) = breg[j];
-        }
+        unsigned char *d = bl[buf] + (size_t)tid * 16;
+        *reinterpret_cast<uint4 *>(d) = b0;
+        *reinterpret_cast<uint4 *>(d + 512 * 16) = b1;
+        *reinterpret_cast<uint4 *>(d + 2 * 512 * 16) = b2;
+        *reinterpret_cast<uint4 *>(d + 3 * 512 * 16) = b3;
+        *reinterpret_cast<uint4 *>(d + 4 * 512 * 16) = b4;
+        if (last_piece) *reinterpret_cast<uint4 *>(d + 5 * 512 * 16) = b5;
     };
     v8 A[2][KS][WM];
     auto load_a = [&](int st, int buf) {
@@ -230,7 +244,14 @@ policy_fc_kernel(const typename E::T *__restrict__ a, const typename E::T *__res
                     load_b(cs + 1);
                     load_a(cs + 1, half ^ 1);
                 }
+                // (pinned, for the optimizer's memory motion and for the scheduler: left alone, the compiler moves the LDS stores of the next stage -- which depend on nothing the
+                // MFMAs produce -- right behind their loads, in FRONT of this stage's 88 MFMAs, and every stage then waits
+                // out a full L2 round trip: 60 % of the wave cycles were s_waitcnt, profiles/r04_heads.md)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
                 compute(half);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" ::: "memory");
                 if (more) store_b(half ^ 1);
             }
             __syncthreads();
