@@ -36,10 +36,19 @@ def movegen_counters():
     k = c["hive_piece_kernel<false,false>"]
     n = c["boards_per_dispatch"]
     valu = k["SQ_INSTS_VALU"] / n
-    return {"file": os.path.relpath(files[-1], ROOT), "source": c["source"],
-            "traffic_bytes_per_board": (c["fetch_size_correction"] * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0 / n,
-            "valu_per_board": valu,
-            "valu_issue_peak_mboards": 1024 * 2.4e9 / (valu * 4) / 1e6}      # 1024 SIMDs, 4 cycles per wave-instruction
+    out = {"file": os.path.relpath(files[-1], ROOT), "source": c["source"],
+           "traffic_bytes_per_board": (c["fetch_size_correction"] * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0 / n,
+           "valu_per_board": valu,
+           "valu_issue_peak_mboards": 1024 * 2.4e9 / (valu * 4) / 1e6}      # 1024 SIMDs, 4 cycles per wave-instruction
+    sat = c.get("saturated")              # the large-launch form of the kernel (pair layout from 16,384 boards on), counted apart
+    if sat:
+        ks = sat["hive_piece_kernel<false,false,PairLay>"]
+        ns = sat["boards_per_dispatch"]
+        out["saturated"] = {"layout": "pair", "valu_per_board": ks["SQ_INSTS_VALU"] / ns,
+                            "valu_issue_peak_mboards": 1024 * 2.4e9 / (ks["SQ_INSTS_VALU"] / ns * 4) / 1e6,
+                            "traffic_bytes_per_board": (c["fetch_size_correction"] * ks["FETCH_SIZE_KiB"] + ks["WRITE_SIZE_KiB"]) * 1024.0 / ns,
+                            "quad_valu_per_board": sat["hive_piece_kernel<false,false,QuadLay>"]["SQ_INSTS_VALU"] / ns}
+    return out
 
 
 def host_cores(cap=16):
@@ -750,13 +759,30 @@ def main():
         s1.record(stream)
         torch.cuda.synchronize()
         ms = s0.elapsed_time(s1) / 10
+        pair_from = L.hive_movegen_pair_threshold(-1)
+        cs = None if ctr is None else (ctr.get("saturated") if nb >= pair_from else ctr)
         sat = {"boards_per_launch": nb, "ms_per_launch": round(ms, 4), "Mboards_per_s": round(nb / ms / 1e3, 2),
+               "lane_layout": "pair (one board = 2 lanes, 32 boards per workgroup)" if nb >= pair_from else "quad",
                "achieved_GBs": round(nb * ALGO_BYTES_PER_BOARD / ms / 1e6, 2),
                "frac_of_hbm_peak": round(nb * ALGO_BYTES_PER_BOARD / ms / 1e6 / HBM_PEAK_GBS, 5),
-               "valu_issue_roof": None if ctr is None else {
-                   "valu_wave_instr_per_board": round(ctr["valu_per_board"], 1),
-                   "peak_Mboards_per_s": round(ctr["valu_issue_peak_mboards"], 1),
-                   "frac": round(nb / ms / 1e3 / ctr["valu_issue_peak_mboards"], 4), "source": ctr["file"]}}
+               "valu_issue_roof": None if cs is None else {
+                   "valu_wave_instr_per_board": round(cs["valu_per_board"], 1),
+                   "peak_Mboards_per_s": round(cs["valu_issue_peak_mboards"], 1),
+                   "frac": round(nb / ms / 1e3 / cs["valu_issue_peak_mboards"], 4), "source": ctr["file"]}}
+        # the same launch held in the quad layout (what round 3 measured here), for the comparison
+        L.hive_movegen_pair_threshold(1 << 30)
+        try:
+            for _ in range(3):
+                L.hive_movegen_launch(*args_big)
+            s0.record(stream)
+            for _ in range(10):
+                L.hive_movegen_launch(*args_big)
+            s1.record(stream)
+            torch.cuda.synchronize()
+        finally:
+            L.hive_movegen_pair_threshold(0)
+        msq = s0.elapsed_time(s1) / 10
+        sat["quad_layout"] = {"ms_per_launch": round(msq, 4), "Mboards_per_s": round(nb / msq / 1e3, 2)}
         del big, bm, bc
 
     # side measurement: the boundary handing over HOST buffers -- pinned boards in, pinned mask + count out, per step
@@ -835,7 +861,7 @@ def main():
                                            "passes of this command, gfx950 FETCH_SIZE correction applied; not measurable in-run)",
                          "kernel": "hive_piece_kernel<false>", "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_BOARD,
-                         "note": "VALU-issue bound (~489 wave-instructions per board), not HBM bound: see saturated.valu_issue_roof; "
+                         "note": "VALU-issue bound (~489 wave-instructions per board in this launch's quad layout), not HBM bound: see saturated.valu_issue_roof; "
                                  "4096 boards = 256 workgroups x 11 waves = one workgroup per CU; the 256 KB corpus is re-read "
                                  "every step, so the read side is served by L2 / Infinity Cache and the HBM label is nominal"},
             "movegen_with_sorted_id_list": with_list,

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "hive_last_error", "hive_version", "hive_device_count", "hive_batch_create", "hive_batch_destroy",
     "hive_batch_size", "hive_batch_set_stream", "hive_batch_reset", "hive_batch_step",
     "hive_batch_illegal_count", "hive_batch_legal", "hive_batch_encode", "hive_batch_terminal",
-    "hive_batch_export", "hive_batch_import", "hive_movegen_launch", "hive_encode_launch",
+    "hive_batch_export", "hive_batch_import", "hive_movegen_launch", "hive_movegen_pair_threshold", "hive_encode_launch",
     "hive_terminal_launch", "hive_step_launch", "hive_step_launch_counted", "hive_leaf_launch", "hive_expand_launch", "hive_leaf_dedup_launch",
     "hive_single_create", "hive_single_destroy", "hive_single_advance", "hive_single_encode",
     "hive_leaf_store_create", "hive_leaf_store_destroy", "hive_leaf_store_clear", "hive_leaf_store_lookup", "hive_leaf_store_update",
@@ -94,6 +94,7 @@ def load():
     L.hive_batch_export.argtypes = [vp, vp, vp]
     L.hive_batch_import.argtypes = [vp, vp, vp]
     L.hive_movegen_launch.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.hive_movegen_pair_threshold.argtypes = [i32]
     L.hive_encode_launch.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
     L.hive_debug_tables.argtypes = [vp, vp, vp]
     L.hive_expand_launch.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp]

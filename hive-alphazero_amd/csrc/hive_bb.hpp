@@ -133,17 +133,82 @@ __device__ __forceinline__ BB shift_dirs(BB a0, BB a1, BB a2, BB a3, BB a4, BB a
     return BB{u2.lo | d5.lo | r.lo | l.lo, u2.hi | d5.hi | r.hi | l.hi};
 }
 
-// Everything a sliding piece needs about the board with the mover lifted off.
-struct SlideCtx {
-    BB cs[6];      // cs[i] bit c: exactly one of the two cells flanking the step c -> c+d_i is occupied
-    BB allowed;    // empty and touching the hive
-    BB nocc;       // cells touching the hive (occupied or not)
+// ---------------------------------------------------------------- the pair layout
+// One board = TWO consecutive lanes, three VGPRs per lane: lane 0 of the pair holds memory words 0-2 (rows 0-5), lane 1
+// words 3-5 (rows 6-11).  A wave carries 32 boards and no lane idles (the quad layout leaves every fourth lane empty), so a
+// board operation costs 3 instructions per 32 boards instead of 2 per 16; the price is a third more registers per board
+// value and a longer wave-level flood loop (the slowest of 32 boards, not of 16).  Used by the movegen kernel for launches
+// large enough to fill the card either way (hive_env.hip: hive_piece_kernel<false, false, PairLay>); measured first on
+// the Ant flood alone (tools/dev/flood_layouts.hip, profiles/r03_flood_layouts.md).
+struct B3 {
+    uint32_t w0, w1, w2;
 };
+constexpr int kPairB0 = 0 | (0 << 2) | (2 << 4) | (2 << 6);     // both lanes of a pair read its lane 0
+
+__device__ __forceinline__ int pair_lane() { return (int)(threadIdx.x & 1u); }
+__device__ __forceinline__ B3 bb_and(B3 a, B3 b) { return B3{a.w0 & b.w0, a.w1 & b.w1, a.w2 & b.w2}; }
+__device__ __forceinline__ B3 bb_or(B3 a, B3 b) { return B3{a.w0 | b.w0, a.w1 | b.w1, a.w2 | b.w2}; }
+__device__ __forceinline__ B3 bb_or3(B3 a, B3 b, B3 c) { return B3{a.w0 | b.w0 | c.w0, a.w1 | b.w1 | c.w1, a.w2 | b.w2 | c.w2}; }
+__device__ __forceinline__ B3 bb_xor(B3 a, B3 b) { return B3{a.w0 ^ b.w0, a.w1 ^ b.w1, a.w2 ^ b.w2}; }
+__device__ __forceinline__ B3 bb_andn(B3 a, B3 b) { return B3{a.w0 & ~b.w0, a.w1 & ~b.w1, a.w2 & ~b.w2}; }
+__device__ __forceinline__ uint32_t pair_or(uint32_t t) { return t | quad<kQuadSwap1>(t); }
+__device__ __forceinline__ bool bb_any(B3 a) { return pair_or(a.w0 | a.w1 | a.w2) != 0u; }
+__device__ __forceinline__ bool bb_eq(B3 a, B3 b) { return pair_or((a.w0 ^ b.w0) | (a.w1 ^ b.w1) | (a.w2 ^ b.w2)) == 0u; }
+__device__ __forceinline__ B3 bb_up(B3 x)
+{
+    uint32_t other2 = quad<kQuadSwap1>(x.w2);
+    return B3{__builtin_amdgcn_alignbit(x.w0, other2, 16), __builtin_amdgcn_alignbit(x.w1, x.w0, 16),
+              __builtin_amdgcn_alignbit(x.w2, x.w1, 16)};
+}
+__device__ __forceinline__ B3 bb_down(B3 x)
+{
+    uint32_t other0 = quad<kQuadSwap1>(x.w0);
+    return B3{__builtin_amdgcn_alignbit(x.w1, x.w0, 16), __builtin_amdgcn_alignbit(x.w2, x.w1, 16),
+              __builtin_amdgcn_alignbit(other0, x.w2, 16)};
+}
+__device__ __forceinline__ B3 bb_right(B3 x) { return B3{col_right(x.w0), col_right(x.w1), col_right(x.w2)}; }
+__device__ __forceinline__ B3 bb_left(B3 x) { return B3{col_left(x.w0), col_left(x.w1), col_left(x.w2)}; }
+__device__ __forceinline__ B3 bb_neighbours(B3 x)
+{
+    B3 u = bb_up(x), d = bb_down(x);
+    B3 r = bb_right(bb_or(x, u));
+    B3 l = bb_left(bb_or(x, d));
+    return B3{u.w0 | d.w0 | r.w0 | l.w0, u.w1 | d.w1 | r.w1 | l.w1, u.w2 | d.w2 | r.w2 | l.w2};
+}
+__device__ __forceinline__ B3 shift_dirs(B3 a0, B3 a1, B3 a2, B3 a3, B3 a4, B3 a5)
+{
+    B3 u2 = bb_up(a2), d5 = bb_down(a5);
+    B3 r = bb_right(bb_or(a0, bb_up(a1)));
+    B3 l = bb_left(bb_or(a3, bb_down(a4)));
+    return B3{u2.w0 | d5.w0 | r.w0 | l.w0, u2.w1 | d5.w1 | r.w1 | l.w1, u2.w2 | d5.w2 | r.w2 | l.w2};
+}
+__device__ __forceinline__ B3 bb_lowest(B3 x)
+{
+    uint32_t l0 = x.w0 & (0u - x.w0);
+    uint32_t l1 = x.w0 ? 0u : (x.w1 & (0u - x.w1));
+    uint32_t l2 = (x.w0 | x.w1) ? 0u : (x.w2 & (0u - x.w2));
+    uint32_t any = x.w0 | x.w1 | x.w2;
+    uint32_t a0 = quad<kPairB0>(any);
+    bool keep = pair_lane() == 0 || a0 == 0u;
+    return B3{keep ? l0 : 0u, keep ? l1 : 0u, keep ? l2 : 0u};
+}
+__device__ __forceinline__ int bb_popc_lane(BB x) { return __popc(x.lo) + __popc(x.hi); }      // this lane's share
+__device__ __forceinline__ int bb_popc_lane(B3 x) { return __popc(x.w0) + __popc(x.w1) + __popc(x.w2); }
+
+// Everything a sliding piece needs about the board with the mover lifted off.
+template <class B>
+struct SlideCtxT {
+    B cs[6];      // cs[i] bit c: exactly one of the two cells flanking the step c -> c+d_i is occupied
+    B allowed;    // empty and touching the hive
+    B nocc;       // cells touching the hive (occupied or not)
+};
+using SlideCtx = SlideCtxT<BB>;
 
 // S_i bit c = occ[c + d_i]
-__device__ __forceinline__ void occupancy_views(BB occ, BB S[6])
+template <class B>
+__device__ __forceinline__ void occupancy_views(B occ, B S[6])
 {
-    BB u = bb_up(occ), d = bb_down(occ);
+    B u = bb_up(occ), d = bb_down(occ);
     S[5] = u;              // occ[c + D]  = occ moved up
     S[2] = d;              // occ[c + U]  = occ moved down
     S[0] = bb_left(occ);   // occ[c + R]
@@ -152,9 +217,10 @@ __device__ __forceinline__ void occupancy_views(BB occ, BB S[6])
     S[4] = bb_right(u);    // occ[c + DL]
 }
 
-__device__ __forceinline__ SlideCtx make_slide_ctx(BB occ, const BB S[6])
+template <class B>
+__device__ __forceinline__ SlideCtxT<B> make_slide_ctx(B occ, const B S[6])
 {
-    SlideCtx c;
+    SlideCtxT<B> c;
     c.cs[0] = bb_xor(S[5], S[1]);
     c.cs[1] = bb_xor(S[0], S[2]);
     c.cs[2] = bb_xor(S[1], S[3]);
@@ -167,12 +233,14 @@ __device__ __forceinline__ SlideCtx make_slide_ctx(BB occ, const BB S[6])
 }
 
 // one slide step of every cell in x: k == 1 gate rule (reference move_checker.py:189-214)
-__device__ __forceinline__ BB slide_raw(const SlideCtx &c, BB x)
+template <class B>
+__device__ __forceinline__ B slide_raw(const SlideCtxT<B> &c, B x)
 {
     return shift_dirs(bb_and(x, c.cs[0]), bb_and(x, c.cs[1]), bb_and(x, c.cs[2]), bb_and(x, c.cs[3]),
                       bb_and(x, c.cs[4]), bb_and(x, c.cs[5]));
 }
-__device__ __forceinline__ BB slide_step(const SlideCtx &c, BB x) { return bb_and(slide_raw(c, x), c.allowed); }
+template <class B>
+__device__ __forceinline__ B slide_step(const SlideCtxT<B> &c, B x) { return bb_and(slide_raw(c, x), c.allowed); }
 
 // lowest set cell of a board (row-major order), as a single-cell board; empty -> empty
 __device__ __forceinline__ BB bb_lowest(BB x)
@@ -204,5 +272,49 @@ __device__ __forceinline__ void bb_store(uint32_t *p, BB v)
         p[2 * l + 1] = v.hi;
     }
 }
+
+
+// The two layouts behind one set of names, for code that is generic over them (hive_env.hip: piece_dests, placement_board).
+struct QuadLay {
+    using B = BB;
+    static constexpr int kLanes = 4;           // lanes per board
+    static constexpr int kShift = 2;
+    static __device__ __forceinline__ int sub() { return quad_lane(); }
+    static __device__ __forceinline__ bool holds() { return quad_lane() < 3; }       // this lane carries words of the board
+    static __device__ __forceinline__ int word0() { return 2 * quad_lane(); }        // its first memory word
+    static __device__ __forceinline__ B zero() { return bb_zero(); }
+    static __device__ __forceinline__ B full() { return bb_full(); }
+    static __device__ __forceinline__ B bit(unsigned cell) { return bb_bit(cell); }
+    static __device__ __forceinline__ B load(const uint32_t *p) { return bb_load(p); }
+    static __device__ __forceinline__ void store(uint32_t *p, B v) { bb_store(p, v); }
+};
+struct PairLay {
+    using B = B3;
+    static constexpr int kLanes = 2;
+    static constexpr int kShift = 1;
+    static __device__ __forceinline__ int sub() { return pair_lane(); }
+    static __device__ __forceinline__ bool holds() { return true; }
+    static __device__ __forceinline__ int word0() { return 3 * pair_lane(); }
+    static __device__ __forceinline__ B zero() { return B3{0u, 0u, 0u}; }
+    static __device__ __forceinline__ B full() { return B3{0x0FFF0FFFu, 0x0FFF0FFFu, 0x0FFF0FFFu}; }
+    static __device__ __forceinline__ B bit(unsigned cell)
+    {
+        unsigned row = cell / 12u, col = cell - row * 12u;
+        unsigned r6 = row >= 6u ? row - 6u : row;
+        uint32_t m = (cell < 144u && (int)(row >= 6u) == pair_lane()) ? (1u << (((r6 & 1u) << 4) | col)) : 0u;
+        unsigned wi = r6 >> 1;
+        return B3{wi == 0u ? m : 0u, wi == 1u ? m : 0u, wi == 2u ? m : 0u};
+    }
+    static __device__ __forceinline__ B load(const uint32_t *p)
+    {
+        const uint32_t *q = p + 3 * pair_lane();
+        return B3{q[0], q[1], q[2]};
+    }
+    static __device__ __forceinline__ void store(uint32_t *p, B v)
+    {
+        uint32_t *q = p + 3 * pair_lane();
+        q[0] = v.w0; q[1] = v.w1; q[2] = v.w2;
+    }
+};
 
 }  // namespace hive

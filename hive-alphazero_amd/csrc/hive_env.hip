@@ -58,6 +58,12 @@ constexpr int NW = 11;                 // waves per workgroup = piece slots per 
 #ifndef HIVE_PIECE_WPE
 #define HIVE_PIECE_WPE 6                // waves per SIMD asked of the register allocator (two 11-wave workgroups per CU)
 #endif
+#ifndef HIVE_PAIR_ANT_STEPS
+#define HIVE_PAIR_ANT_STEPS HIVE_ANT_STEPS
+#endif
+#ifndef HIVE_PAIR_WPE
+#define HIVE_PAIR_WPE 6                 // ... of the pair-layout variant (three registers per board value instead of two)
+#endif
 constexpr unsigned kHand = 255u;
 constexpr int kPinWaves = 3;           // waves 0-2 run the one-hive test for all 176 (board, piece) items of a workgroup
 
@@ -77,9 +83,10 @@ __device__ __forceinline__ int slot_group_start(int slot)
 // quads.  FULL = false: 16 boards per workgroup, quad = board, wave = slot of the side to move.
 // FULL = true : 8 boards per workgroup, quads 0-7 = white piece, 8-15 = black piece of slot
 // `wave` (both colours are needed by the planes).
-template <bool FULL>
+// Pair layout (movegen only, hive_bb.hpp): 32 boards per workgroup, pair = board.
+template <bool FULL, int GB = (FULL ? 8 : 16)>
 struct alignas(16) Smem {
-    static constexpr int G = FULL ? 8 : 16;
+    static constexpr int G = GB;
     uint32_t state[G][16];       // HiveBoard records
     uint32_t occ[G][6];          // cells with at least one piece
     uint32_t topw[G][6];         // cells whose top piece is white
@@ -111,8 +118,9 @@ __device__ __forceinline__ bool obeys_queen_by_4(unsigned turn, int nq, int firs
            (first_color == 1 && turn == 8) || (first_color == 0 && turn == 8 && mover_queen);
 }
 
-struct PieceInfo {
-    BB D;            // final destination set
+template <class B>
+struct PieceInfoT {
+    B D;             // final destination set
     unsigned cell;   // kHand if in hand
     unsigned lvl, h;
     bool on_board, on_top, pinned;
@@ -122,11 +130,12 @@ struct PieceInfo {
 // `type` and the loops' trip tests are wave-uniform.
 // own == true : get_actions semantics (env_hive.py:207-285)
 // own == false: mini_black_actions semantics for an enemy piece (env_hive.py:449-485)
-template <int ANT_STEPS>
-__device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint32_t *occ_p, const uint8_t *pinfo, const uint32_t *pinmask_p, const int *pin_done_p,
+template <int ANT_STEPS, class L = QuadLay>
+__device__ __forceinline__ PieceInfoT<typename L::B> piece_dests(const uint32_t *st, const uint32_t *occ_p, const uint8_t *pinfo, const uint32_t *pinmask_p, const int *pin_done_p,
                                                  const uint32_t *place_p, int q, int type, bool own, bool valid)
 {
-    PieceInfo out;
+    using BB = typename L::B;
+    PieceInfoT<BB> out;
     const unsigned turn = state_byte(st, 33);
     const int stm = (turn & 1u) ? 0 : 1;
     const int color = q >= 11 ? 1 : 0, slot = q - 11 * color;
@@ -146,10 +155,14 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     const int first_color = wq ? 0 : 1;
     const bool stm_queen = stm == 0 ? wq : bq;
 
-    const BB occ = bb_load(occ_p);
-    const BB srcbit = bb_bit(on_board ? c : 255u);
+    const BB occ = L::load(occ_p);
+    const BB srcbit = L::bit(on_board ? c : 255u);
     const BB occp = (on_board && !stacked) ? bb_xor(occ, srcbit) : occ;
-    const BB nsrc = on_board ? bb_load(d_tables.nmask[c]) : bb_zero();      // the six neighbours of src
+    // the six neighbours of src.  Pair layout: three registers per board value and the same 80-register budget, so what
+    // is only needed behind the loops (nsrc, occ) is fetched again there instead of being carried (or spilled) through them
+    constexpr bool kLate = L::kLanes == 2;
+    auto load_nsrc = [&]() { return on_board ? L::load(d_tables.nmask[c]) : L::zero(); };
+    const BB nsrc = kLate ? L::zero() : load_nsrc();
 
     // The one-hive test (move_checker.py:58-83 / env_hive.py:509-530) is not made here: the pin waves
     // (pin_phase below) decide it for every piece of the workgroup on the 22-node piece graph while
@@ -158,11 +171,11 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     int dbg_it = 0; (void)dbg_it;
 
     // ---- piece rule (pieces.py) on the board with the mover lifted
-    BB rule = bb_zero();
+    BB rule = L::zero();
     if (type == T_GRASS) {
         // pieces.py:128-158: flood from src through occupied cells on a "line" from src
-        BB L = bb_load(d_tables.line[on_board ? c : 0u]);
-        BB Lo = bb_and(L, occ);
+        BB Ln = L::load(d_tables.line[on_board ? c : 0u]);
+        BB Lo = bb_and(Ln, occ);
         BB V = srcbit;
         bool ga = on_top;
         while (__any(ga)) {
@@ -174,11 +187,12 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 V = nx;
             }
         }
-        rule = bb_andn(bb_and(bb_andn(bb_neighbours(V), occ), L), nsrc);
+        if constexpr (kLate) rule = bb_andn(bb_and(bb_andn(bb_neighbours(V), L::load(occ_p)), L::load(d_tables.line[on_board ? c : 0u])), load_nsrc());
+        else rule = bb_andn(bb_and(bb_andn(bb_neighbours(V), occ), Ln), nsrc);
     } else {
         BB S[6];
         occupancy_views(occp, S);
-        SlideCtx ctx = make_slide_ctx(occp, S);
+        SlideCtxT<BB> ctx = make_slide_ctx(occp, S);
         if (type == T_QUEEN) {
             rule = slide_step(ctx, srcbit);                       // pieces.py:35-44
         } else if (type == T_ANT) {
@@ -205,7 +219,7 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 // pieces.py:78-85: simple path of exactly three k==1 steps, then the direct-hop veto.
                 // For each first step a: {c} = slide(slide(a) \ src) \ {src, a}; c != b holds by itself.
                 BB A = slide_step(ctx, srcbit);
-                BB acc = bb_zero();
+                BB acc = L::zero();
                 bool sa = on_top && bb_any(A);
                 while (__any(sa)) {
                     HIVE_COUNT_ITER();
@@ -227,8 +241,9 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
                 BB Q0 = shift_dirs(bb_andn(bb_andn(srcbit, ctx.cs[0]), b0), bb_andn(bb_andn(srcbit, ctx.cs[1]), b1),
                                    bb_andn(bb_andn(srcbit, ctx.cs[2]), b2), bb_andn(bb_andn(srcbit, ctx.cs[3]), b3),
                                    bb_andn(bb_andn(srcbit, ctx.cs[4]), b4), bb_andn(bb_andn(srcbit, ctx.cs[5]), b5));
-                rule = bb_or3(bb_and(nsrc, occ), Q1, bb_and(Q0, ctx.nocc));
-                if (stacked) rule = bb_or(rule, nsrc);
+                const BB nb = kLate ? load_nsrc() : nsrc;
+                rule = bb_or3(bb_and(nb, occ), Q1, bb_and(Q0, ctx.nocc));
+                if (stacked) rule = bb_or(rule, nb);
             }
         }
     }
@@ -252,7 +267,7 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
     if (turn >= 3u && turn <= 6u) gate = in_hand || stm_queen;                      // queen_is_on_board
     else if (turn == 7u || turn == 8u) gate = obeys_queen_by_4(turn, nq, first_color, type == T_QUEEN, color);
 
-    BB D = bb_zero();
+    BB D = L::zero();
     if (valid && in_hand) {
         if (own) {
             // only the first in-hand piece of each type emits placements (env_hive.py:218-219)
@@ -261,18 +276,19 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
             if (slot > g0) first = state_byte(st, (unsigned)(color * 11 + g0)) < (unsigned)kCells;
             if (slot > g0 + 1) first = first && state_byte(st, (unsigned)(color * 11 + g0 + 1)) < (unsigned)kCells;
             // the destinations are the same for every piece in the mover's hand: placement_board() built them once
-            if (first && (turn <= 2u || gate)) D = bb_load(place_p);
+            if (first && (turn <= 2u || gate)) D = L::load(place_p);
         }
     } else if (movable) {
         const bool adjacent_domain = (type == T_QUEEN || type == T_BEETLE);
         BB domain;
-        if (!own) domain = bb_full();
-        else if (adjacent_domain) domain = nsrc;
-        else domain = bb_load(place_p + 6);       // next_move_tiles (env_hive.py:66-69,150-161), shared per board
+        if (!own) domain = L::full();
+        else if (adjacent_domain) domain = kLate ? load_nsrc() : nsrc;
+        else domain = L::load(place_p + 6);       // next_move_tiles (env_hive.py:66-69,150-161), shared per board
         if (turn <= 2u) {
-            BB base = bb_andn(type == T_BEETLE ? bb_full() : bb_not(occ), srcbit);
+            const BB occ2 = kLate ? L::load(occ_p) : occ;
+            BB base = bb_andn(type == T_BEETLE ? L::full() : bb_andn(L::full(), occ2), srcbit);
             D = bb_and(domain, base);
-            D = bb_and(D, turn == 1u ? bb_bit((unsigned)kStartCell) : bb_neighbours(occ));
+            D = bb_and(D, turn == 1u ? L::bit((unsigned)kStartCell) : bb_neighbours(occ2));
         } else if (gate) {
             D = bb_and(rule, domain);
         }
@@ -291,21 +307,24 @@ __device__ __forceinline__ PieceInfo piece_dests(const uint32_t *st, const uint3
 // quad per board: turn 1 the start tile, turn 2 any empty tile of next_move_tiles next to the hive (colour rule waived),
 // later empty hive-adjacent tiles none of whose neighbours is topped by the other colour.  The turn gate (queen rules)
 // is per piece type and applied by the reader.
-__device__ __forceinline__ BB placement_board(const uint32_t *st, const uint32_t *occ_p, const uint32_t *topw_p, BB &nmt)
+template <class L = QuadLay>
+__device__ __forceinline__ typename L::B placement_board(const uint32_t *st, const uint32_t *occ_p, const uint32_t *topw_p,
+                                                         typename L::B &nmt)
 {
+    using BB = typename L::B;
     const unsigned turn = state_byte(st, 33);
     const unsigned mode = state_byte(st, 34) & 3u;
     const int stm = (turn & 1u) ? 0 : 1;
-    const BB occ = bb_load(occ_p);
+    const BB occ = L::load(occ_p);
     const BB nocc = bb_neighbours(occ);
     const BB empty_adj = bb_andn(nocc, occ);
     nmt = empty_adj;                            // next_move_tiles (env_hive.py:66-69,150-161)
-    if (mode == 1u) nmt = bb_bit((unsigned)kStartCell);
-    else if (mode == 2u) nmt = bb_and(empty_adj, bb_bit((unsigned)kTurn2Cell));
+    if (mode == 1u) nmt = L::bit((unsigned)kStartCell);
+    else if (mode == 2u) nmt = bb_and(empty_adj, L::bit((unsigned)kTurn2Cell));
     const BB base = bb_andn(nmt, occ);
-    if (turn == 1u) return bb_and(base, bb_bit((unsigned)kStartCell));
+    if (turn == 1u) return bb_and(base, L::bit((unsigned)kStartCell));
     if (turn == 2u) return bb_and(base, nocc);
-    const BB topw = bb_load(topw_p);
+    const BB topw = L::load(topw_p);
     const BB top_enemy = stm == 0 ? bb_andn(occ, topw) : topw;
     return bb_andn(bb_and(base, nocc), bb_neighbours(top_enemy));
 }
@@ -319,10 +338,11 @@ __device__ __forceinline__ BB placement_board(const uint32_t *st, const uint32_t
 // adjacency rows of its board in registers and floods a 22-bit reach mask with alternating
 // ascending / descending Gauss-Seidel sweeps (two instructions per row) until every neighbour of
 // the lifted piece is reached (free) or nothing grows (pinned).
-template <bool FULL>
-__device__ __forceinline__ void pin_phase(Smem<FULL> &sm, int wave, int lane)
+// 32 boards per workgroup (the pair layout) are two passes of the three pin waves over the 352 items.
+template <bool FULL, class SM>
+__device__ __forceinline__ void pin_phase(SM &sm, int wave, int lane)
 {
-    constexpr int G = Smem<FULL>::G;
+    constexpr int G = SM::G;
     // piece graph first: row q = the pieces on q's cell and on its six neighbour cells (G x 22 rows, two per lane);
     // the other eight waves are already at their piece work and never wait for this
     for (int r = wave * 64 + lane; r < G * 22; r += kPinWaves * 64) {
@@ -343,8 +363,11 @@ __device__ __forceinline__ void pin_phase(Smem<FULL> &sm, int wave, int lane)
     while (__hip_atomic_load(&sm.adj_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kPinWaves)
         __builtin_amdgcn_s_sleep(1);
 
-    const int item = wave * 64 + lane;                 // 176 items: G boards x (FULL ? 22 : 11) pieces
-    const int per = FULL ? 22 : 11;
+    constexpr int per = FULL ? 22 : 11;
+    constexpr int kPasses = (G * per + kPinWaves * 64 - 1) / (kPinWaves * 64);
+#pragma unroll 1
+    for (int pass = 0; pass < kPasses; ++pass) {
+    const int item = pass * (kPinWaves * 64) + wave * 64 + lane;      // 176 items: G boards x (FULL ? 22 : 11) pieces
     int b = item / per;
     const bool ok = b < G;
     if (!ok) b = G - 1;
@@ -394,6 +417,7 @@ __device__ __forceinline__ void pin_phase(Smem<FULL> &sm, int wave, int lane)
     }
 #endif
     if (pinned) atomicOr(&sm.pinmask[b], 1u << q);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) __hip_atomic_fetch_add(&sm.pin_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -469,10 +493,10 @@ __device__ __forceinline__ void emit_id_list(const uint32_t *img, const uint32_t
 }
 
 // LDS of the fused list variant: the destination images of the workgroup's 16 boards and one list row per wave
-template <bool LIST> struct ListMem { uint32_t pad; };
-template <> struct alignas(16) ListMem<true> {
-    uint32_t dest[16][11][6];
-    uint32_t any[16][6];                   // OR of a board's eleven destination boards
+template <bool LIST, int G> struct ListMem { uint32_t pad; };
+template <int G> struct alignas(16) ListMem<true, G> {
+    uint32_t dest[G][11][6];
+    uint32_t any[G][6];                    // OR of a board's eleven destination boards
     uint8_t cells[NW][kCells];             // per list-building wave: the cells that are somebody's destination
     alignas(8) int16_t rowbuf[NW][HIVE_LIST_CAP];
 };
@@ -485,18 +509,23 @@ template <> struct alignas(16) ListMem<true> {
 // LIST = true (movegen only): the sorted id list (GamePlay.actions() itself) leaves the same launch: the destination
 // boards are also kept in LDS, the waves meet at one barrier and build the lists of the workgroup's 16 boards between
 // them -- no second launch, no re-read of the mask.
-template <bool FULL, bool LIST = false>
-__global__ void __launch_bounds__(NW * 64, FULL ? 5 : HIVE_PIECE_WPE)
+// L = PairLay (movegen without the list only): one board = two lanes, 32 boards per workgroup -- a quarter fewer VALU
+// instructions per board, for launches that fill the card in either layout (hive_movegen_launch picks it from
+// kPairFromBoards on; a 4096-board launch is one quad workgroup per CU and would leave half the CUs idle in pairs).
+template <bool FULL, bool LIST = false, class L = QuadLay>
+__global__ void __launch_bounds__(NW * 64, FULL ? 5 : (L::kLanes == 2 ? HIVE_PAIR_WPE : HIVE_PIECE_WPE))
 hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restrict__ mask,
                   int32_t *__restrict__ count, unsigned long long *__restrict__ feat, int16_t *__restrict__ list)
 {
     static_assert(!(FULL && LIST), "the fused list belongs to the movegen variant");
-    __shared__ Smem<FULL> sm;
-    __shared__ ListMem<LIST> lm;
-    constexpr int G = Smem<FULL>::G;
+    static_assert(L::kLanes == 4 || !FULL, "the pair layout is built for the movegen variant");
+    using BB = typename L::B;
+    constexpr int G = FULL ? 8 : 64 / L::kLanes;
+    __shared__ Smem<FULL, G> sm;
+    __shared__ ListMem<LIST, G> lm;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int item = lane >> 2;                      // quad index inside the wave
+    const int item = lane >> L::kShift;              // quad (pair) index inside the wave
     const int bl = FULL ? (item & 7) : item;         // board of this quad inside the workgroup
     // wave -> piece slot.  Waves land on SIMD (wave id mod 4) and start in id order: waves 0-2 are the Queen and the
     // Beetles (they run the pin phase first), then the three Ants start early on three different SIMDs, the Spiders
@@ -509,7 +538,10 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
 #define HIVE_PIN_IDS 0xFFFFFFFF210ull         /* hex digit w = share (0..2) of the one-hive test wave w takes first, F = none */
 #endif
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wv = (int)((HIVE_WAVE_SLOTS >> (4 * wave_id)) & 15ull);      // the piece slot this wave works on
+#ifndef HIVE_PAIR_WAVE_SLOTS
+#define HIVE_PAIR_WAVE_SLOTS HIVE_WAVE_SLOTS
+#endif
+    const int wv = (int)(((L::kLanes == 2 ? HIVE_PAIR_WAVE_SLOTS : HIVE_WAVE_SLOTS) >> (4 * wave_id)) & 15ull);      // the piece slot this wave works on
     const int pin_id = (int)((HIVE_PIN_IDS >> (4 * wave_id)) & 15ull);
     const int nthreads = NW * 64;
     const long long gbase = (long long)blockIdx.x * G;
@@ -537,7 +569,7 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     for (int i = tid; i < G * kCells / 4; i += nthreads)
         reinterpret_cast<uint4 *>(&sm.cellmask[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
     if constexpr (LIST)
-        if (tid < 16 * 6) (&lm.any[0][0])[tid] = 0u;
+        if (tid < G * 6) (&lm.any[0][0])[tid] = 0u;
     if (tid == 0) { sm.done = 0; sm.pin_done = 0; sm.adj_done = 0; }
     if (tid < G) { sm.nlegal[tid] = 0; sm.pinmask[tid] = 0u; }
     if (tid < G * 4) reinterpret_cast<uint4 *>(sm.state[tid >> 2])[tid & 3] = rec_part;
@@ -579,9 +611,9 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     const int type = slot_type(wv);
     if (pin_id == kPinWaves - 1) {       // published together with this wave's pin results (pin_done)
         BB nmt;
-        const BB pl = placement_board(sm.state[bl], sm.occ[bl], sm.topw[bl], nmt);
-        bb_store(sm.place[bl], pl);
-        bb_store(sm.place[bl] + 6, nmt);
+        const BB pl = placement_board<L>(sm.state[bl], sm.occ[bl], sm.topw[bl], nmt);
+        L::store(sm.place[bl], pl);
+        L::store(sm.place[bl] + 6, nmt);
     }
     if (pin_id < kPinWaves) {
         // the three lightest waves (Queen, Beetles) settle the one-hive question for the whole workgroup first
@@ -592,26 +624,42 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     bool own;
     if (!FULL) { q = stm * 11 + wv; own = true; }
     else { int col = item >> 3; q = col * 11 + wv; own = (col == stm); }
-    PieceInfo pc = piece_dests<HIVE_ANT_STEPS>(st, sm.occ[bl], sm.pinfo[bl], &sm.pinmask[bl], &sm.pin_done, sm.place[bl], q,
+    PieceInfoT<BB> pc = piece_dests<(L::kLanes == 2 ? HIVE_PAIR_ANT_STEPS : HIVE_ANT_STEPS), L>(st, sm.occ[bl], sm.pinfo[bl], &sm.pinmask[bl], &sm.pin_done, sm.place[bl], q,
                                                            type, own, valid);
     HIVE_STAMP(1);
     if (own && (mask != nullptr || count != nullptr)) {
         // the legal set leaves as it is: slot wv's destination board, two words per lane, straight to HBM
+        if constexpr (L::kLanes == 4) {
         if (valid && mask != nullptr && (lane & 3) < 3)
             *reinterpret_cast<uint2 *>(mask + (gbase + bl) * HIVE_MASK_WORDS + wv * 6 + 2 * (lane & 3)) =
                 make_uint2(pc.D.lo, pc.D.hi);
-        if constexpr (LIST)       // ... and stays in LDS for the list builders (every (board, slot) quad writes: no clearing)
+        } else {
+            if (valid && mask != nullptr) {      // three words per lane (12-byte pieces, 4-byte aligned)
+                uint32_t *mp = mask + (gbase + bl) * HIVE_MASK_WORDS + wv * 6 + 3 * (lane & 1);
+                mp[0] = pc.D.w0; mp[1] = pc.D.w1; mp[2] = pc.D.w2;
+            }
+        }
+        if constexpr (LIST) {     // ... and stays in LDS for the list builders (every (board, slot) quad writes: no clearing)
+            if constexpr (L::kLanes == 4) {
             if ((lane & 3) < 3) {
                 *reinterpret_cast<uint2 *>(&lm.dest[bl][wv][2 * (lane & 3)]) = make_uint2(pc.D.lo, pc.D.hi);
                 if (pc.D.lo) atomicOr(&lm.any[bl][2 * (lane & 3)], pc.D.lo);
                 if (pc.D.hi) atomicOr(&lm.any[bl][2 * (lane & 3) + 1], pc.D.hi);
             }
-        const int nd = __popc(pc.D.lo) + __popc(pc.D.hi);       // destination sets of different pieces are disjoint
+            } else {
+                uint32_t *dp = &lm.dest[bl][wv][3 * (lane & 1)], *ap = &lm.any[bl][3 * (lane & 1)];
+                dp[0] = pc.D.w0; dp[1] = pc.D.w1; dp[2] = pc.D.w2;
+                if (pc.D.w0) atomicOr(ap, pc.D.w0);
+                if (pc.D.w1) atomicOr(ap + 1, pc.D.w1);
+                if (pc.D.w2) atomicOr(ap + 2, pc.D.w2);
+            }
+        }
+        const int nd = bb_popc_lane(pc.D);                      // destination sets of different pieces are disjoint
         if (nd) atomicAdd(&sm.nlegal[bl], nd);
     }
     HIVE_STAMP(2);
 
-    if (FULL) {
+    if constexpr (FULL) {
         // ---------------- per-piece feature bits (env_hive.py:352-429)
         const BB occ = bb_load(sm.occ[bl]);
         const bool d_any = bb_any(pc.D);
@@ -667,9 +715,18 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
         if (wave_id == 0 && count != nullptr && lane < nbl) count[gbase + lane] = sm.nlegal[lane];
         // 16 boards on 11 waves, four per SIMD (waves land on SIMD wave_id mod 4: SIMD 3 holds two waves, the others three):
         // every wave builds board wave_id, waves 3 and 7 (SIMD 3) and one wave of each other SIMD (4, 5, 6) a second one
-        static_assert(G == 16 || !LIST, "the list builders are shared out for 16 boards on 11 waves");
+        static_assert(G == 16 || G == 32 || !LIST, "the list builders are shared out for 16 or 32 boards on 11 waves");
         // (two boards in lock step inside one wave, and 16 boards as 16 equal shares, were built and measured: 9.24 us
         // against 9.27 -- the eleven waves together are short of VALU issue slots here, not of latency hiding)
+        if constexpr (G == 32) {
+            // 32 boards on 11 waves: three rounds (wave w builds boards w, w + 11, w + 22; 33 turns for 32 boards)
+#pragma unroll 1
+            for (int b = wave_id; b < nbl; b += NW)
+                emit_id_list(&lm.dest[b][0][0], lm.any[b], lm.cells[wave_id], lm.rowbuf[wave_id],
+                             list + (gbase + b) * HIVE_LIST_CAP, lane);
+            HIVE_STAMP(7);
+            return;
+        }
         if (wave_id < nbl)
             emit_id_list(&lm.dest[wave_id][0][0], lm.any[wave_id], lm.cells[wave_id], lm.rowbuf[wave_id],
                          list + (gbase + wave_id) * HIVE_LIST_CAP, lane);
@@ -1059,6 +1116,12 @@ int hive_device_count(void)
     return c;
 }
 
+// Launches of at least this many boards (mask / count, no id list) run in the pair layout.  16,384 boards = 512 pair
+// workgroups = two per CU, the residency the kernel is built for; below that the quad layout's 16-board workgroups
+// spread the same boards over twice as many CUs.
+constexpr int kPairFromBoards = 16384;
+static int g_pair_from = kPairFromBoards;
+
 static int launch_pieces(const HiveBoard *boards, int n, uint32_t *mask, int32_t *count, int16_t *list,
                          hipStream_t stream)
 {
@@ -1066,9 +1129,15 @@ static int launch_pieces(const HiveBoard *boards, int n, uint32_t *mask, int32_t
     if (list != nullptr && mask == nullptr) return fail(HIVE_E_ARG, "movegen: the id list needs the mask buffer too");
     if (list != nullptr && ((uintptr_t)list & 7u) != 0)
         return fail(HIVE_E_ARG, "movegen: the id list must be 8-byte aligned (rows leave as 8-byte stores)");
-    if (list != nullptr)      // mask, count and the sorted id lists in ONE launch (hive_piece_kernel<false, true>)
+    if (list != nullptr && n >= g_pair_from)
+        hipLaunchKernelGGL((hive_piece_kernel<false, true, PairLay>), dim3((unsigned)((n + 31) / 32)), dim3(NW * 64), 0, stream,
+                           boards, n, mask, count, (unsigned long long *)nullptr, list);
+    else if (list != nullptr) // mask, count and the sorted id lists in ONE launch (hive_piece_kernel<false, true>)
         hipLaunchKernelGGL((hive_piece_kernel<false, true>), dim3((unsigned)((n + 15) / 16)), dim3(NW * 64), 0, stream, boards, n,
                            mask, count, (unsigned long long *)nullptr, list);
+    else if (n >= g_pair_from)      // enough boards to fill the card with 32-board workgroups: the pair layout
+        hipLaunchKernelGGL((hive_piece_kernel<false, false, PairLay>), dim3((unsigned)((n + 31) / 32)), dim3(NW * 64), 0, stream,
+                           boards, n, mask, count, (unsigned long long *)nullptr, (int16_t *)nullptr);
     else
         hipLaunchKernelGGL((hive_piece_kernel<false, false>), dim3((unsigned)((n + 15) / 16)), dim3(NW * 64), 0, stream, boards, n,
                            mask, count, (unsigned long long *)nullptr, (int16_t *)nullptr);
@@ -1102,6 +1171,14 @@ static int launch_encode(const HiveBoard *boards, const HiveHistory *hist, int n
 int hive_movegen_launch(const HiveBoard *boards, int n, uint32_t *mask, int32_t *count, int16_t *list, void *stream)
 {
     return launch_pieces(boards, n, mask, count, list, (hipStream_t)stream);
+}
+
+int hive_movegen_pair_threshold(int boards)
+{
+    const int prev = g_pair_from;
+    if (boards > 0) g_pair_from = boards;
+    else if (boards == 0) g_pair_from = kPairFromBoards;
+    return prev;
 }
 
 int hive_encode_launch(const HiveBoard *boards, const HiveHistory *hist, int n, void *planes, HiveDType dtype,

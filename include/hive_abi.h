@@ -140,6 +140,11 @@ int hive_movegen_launch(const HiveBoard *boards, int n, uint32_t *mask, int32_t 
 /* (list, when given, must be 8-byte aligned -- its rows of HIVE_LIST_CAP ids leave the kernel as 8-byte stores; a
  * misaligned pointer is refused with HIVE_E_ARG.  With list != NULL the mask, the counts and the sorted id lists are
  * produced by ONE launch.) */
+/* Launches without an id list of at least this many boards run the kernel's pair layout (one board = two lanes, 32
+ * boards per workgroup: fewer instructions per board once the card is full either way; same bits).  boards > 0 sets the
+ * threshold (INT_MAX: never), 0 restores the default (16384), < 0 only asks; returns the previous value.  Process-wide;
+ * meant for tests and measurements, not for the hot path. */
+int hive_movegen_pair_threshold(int boards);
 /* workspace = device scratch of n * HIVE_CELLS * 8 bytes (the packed 56-bit-per-cell features). */
 int hive_encode_launch(const HiveBoard *boards, const HiveHistory *hist, int n, void *planes,
                        HiveDType dtype, HiveLayout layout, void *workspace, void *stream);

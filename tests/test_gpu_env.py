@@ -275,6 +275,59 @@ def test_movegen_4096_vs_oracle(hv):
         assert _mask_rows_to_lists(m2) == legal[:n]
 
 
+def test_movegen_pair_layout_equals_quad_layout_and_oracle(hv, golden_games):
+    """Launches of >= 16,384 boards run the kernel's pair layout (one board = two lanes, 32 boards per
+    workgroup: hive_bb.hpp).  Forced on at every size here: the reference's golden positions, the 4096-board oracle
+    corpus, ragged tails (1 .. 127 boards: a workgroup's 32 slots partly empty), and the default switch at 16,384."""
+    h, batch, packing = hv
+    L = h.load()
+    prev = L.hive_movegen_pair_threshold(1)
+    try:
+        assert L.hive_movegen_pair_threshold(-1) == 1
+        recs, turn, pos, lvl, mode = _golden_positions(golden_games)
+        boards = torch.from_numpy(packing.pack_boards(turn, pos, lvl, mode)).cuda()
+        mask, count, _ = batch.movegen(boards)
+        got = _mask_rows_to_lists(mask)
+        assert [g for g in got] == [r["legal"] for r in recs]
+        assert count.cpu().numpy().tolist() == [len(r["legal"]) for r in recs]
+
+        turn, pos, lvl, mode, legal = _oracle_corpus(4096, seed=1234)
+        boards = torch.from_numpy(packing.pack_boards(turn, pos, lvl, mode)).cuda()
+        mask, count, _ = batch.movegen(boards)
+        assert _mask_rows_to_lists(mask) == legal
+        assert count.cpu().numpy().tolist() == [len(x) for x in legal]
+        for n in (1, 2, 31, 33, 63, 65, 127):
+            for want_list in (False, True):
+                m2, c2, l2 = batch.movegen(boards[:n].contiguous(), want_list=want_list)
+                assert _mask_rows_to_lists(m2) == legal[:n]
+                assert c2.cpu().numpy().tolist() == [len(x) for x in legal[:n]]
+                if want_list:
+                    l2 = l2.cpu().numpy()
+                    for i in range(n):
+                        assert l2[i, :len(legal[i])].tolist() == legal[i] and np.all(l2[i, len(legal[i]):] == -1)
+        # the fused id list in pairs (32 boards' lists shared out over the 11 waves)
+        m3, c3, l3 = batch.movegen(boards, want_list=True)
+        assert torch.equal(m3, mask) and torch.equal(c3, count)
+        l3 = l3.cpu().numpy()
+        for i in range(4096):
+            assert l3[i, :len(legal[i])].tolist() == legal[i] and np.all(l3[i, len(legal[i]):] == -1)
+        L.hive_movegen_pair_threshold(1 << 30)
+        mq, cq, lq = batch.movegen(boards, want_list=True)
+        assert torch.equal(mq, mask) and torch.equal(cq, count) and np.array_equal(lq.cpu().numpy(), l3)
+    finally:
+        L.hive_movegen_pair_threshold(0)
+    assert L.hive_movegen_pair_threshold(-1) == 16384 and prev == 16384
+    # the default switch: 16,384 boards go through pairs, 16,383 through quads; same bits either way
+    from hive_alphazero_amd import playout
+    base = playout.random_positions(4096, seed=78)
+    big = base.repeat(4, 1).contiguous()
+    m0, c0, _ = batch.movegen(base)
+    mp, cp, lp = batch.movegen(big, want_list=True)
+    mq, cq, lq = batch.movegen(big[:16383].contiguous(), want_list=True)
+    assert torch.equal(mp, m0.repeat(4, 1)) and torch.equal(cp, c0.repeat(4))
+    assert torch.equal(mq, mp[:16383]) and torch.equal(cq, cp[:16383]) and torch.equal(lq, lp[:16383])
+
+
 def test_random_playout_vs_oracle_lockstep(hv):
     """256 games stepped on the GPU and in the oracle with the same actions; every ply compared
     (legal sets, planes, terminal flags), including passes and finished games."""
