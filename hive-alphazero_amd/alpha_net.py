@@ -138,18 +138,22 @@ def train(net, dataset, epoch_start=0, epoch_stop=10, cpu=0, batch_size=512, lr=
 
 
 def _cl_rows(t):
-    """[B,256,12,12] channels-last bf16 tensor -> (contiguous-as-[B*144][256] tensor, rows)."""
+    """[B,C,12,12] channels-last bf16 tensor -> (contiguous-as-[B*144][C] tensor, rows)."""
     if t.dtype != torch.bfloat16 or not t.is_contiguous(memory_format=torch.channels_last):
         t = t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     return t, t.shape[0] * t.shape[2] * t.shape[3]
 
 
 class _BNAct(torch.autograd.Function):
-    """Training-mode BatchNorm2d(256) [+ skip] [+ ReLU] on the hand-written HIP kernels (csrc/hive_train.hip,
-    include/hive_nn.h): bf16 channels-last activations, fp32 statistics and parameter gradients."""
+    """Training-mode BatchNorm2d(C) [+ skip] [+ ReLU] on the hand-written HIP kernels (csrc/hive_train.hip,
+    include/hive_nn.h): bf16 channels-last activations, fp32 statistics and parameter gradients.  C = 256 (the tower) or a
+    smaller power of two (the heads' 128 and 1; bn_act_ok tells whether a shape qualifies)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, bn, relu):
+    def forward(ctx, x, gamma, beta, residual, bn, relu, track=True, link=None):
+        """link: a dict shared with the _Conv3x3 that consumes the same `residual` tensor (a residual block's first
+        convolution): the backward then leaves the skip gradient there instead of returning it, and that convolution's
+        data gradient adds it in its epilogue (one pass instead of a convolution and autograd's elementwise add)."""
         from . import _lib
         L = _lib.load()
         x, rows = _cl_rows(x)
@@ -157,17 +161,20 @@ class _BNAct(torch.autograd.Function):
         if residual is not None:
             res, _ = _cl_rows(residual)
         dev = x.device
+        C = x.shape[1]
         y = torch.empty_like(x)
-        mean = torch.empty(256, dtype=torch.float32, device=dev)
-        invstd = torch.empty(256, dtype=torch.float32, device=dev)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
         ws = torch.empty(L.hive_nn_bn_workspace_floats(), dtype=torch.float32, device=dev)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         _lib.check(L.hive_nn_bn_act_fwd(p(x), p(res), p(gamma), p(beta), p(bn.running_mean), p(bn.running_var),
-                                        float(bn.momentum), float(bn.eps), p(y), p(mean), p(invstd), p(ws), rows, 256,
+                                        float(bn.momentum), float(bn.eps), p(y), p(mean), p(invstd), p(ws), rows, C,
                                         int(relu), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        bn.num_batches_tracked += 1
+        if track:
+            bn.num_batches_tracked += 1
         ctx.save_for_backward(x, y, gamma, mean, invstd)
         ctx.relu, ctx.has_res, ctx.rows = bool(relu), residual is not None, rows
+        ctx.link = link if residual is not None else None
         return y
 
     @staticmethod
@@ -177,16 +184,20 @@ class _BNAct(torch.autograd.Function):
         x, y, gamma, mean, invstd = ctx.saved_tensors
         dy, _ = _cl_rows(dy)
         dev = x.device
+        C = x.shape[1]
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
-        dgamma = torch.empty(256, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(256, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         ws = torch.empty(L.hive_nn_bn_workspace_floats(), dtype=torch.float32, device=dev)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         _lib.check(L.hive_nn_bn_act_bwd(p(dy), p(x), p(y), p(gamma), p(mean), p(invstd), p(dx), p(dres), p(dgamma),
-                                        p(dbeta), p(ws), ctx.rows, 256, int(ctx.relu),
+                                        p(dbeta), p(ws), ctx.rows, C, int(ctx.relu),
                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        return dx, dgamma, dbeta, dres, None, None
+        if ctx.link is not None:
+            ctx.link["dres"] = dres                 # picked up (and added to its own dx) by the linked convolution's backward
+            dres = None
+        return dx, dgamma, dbeta, dres, None, None, None, None
 
 
 _CONST_CACHE = {}
@@ -214,7 +225,9 @@ class _Conv3x3(torch.autograd.Function):
     asm_conv = True          # forward / data gradient of the 256 -> 256 convolutions on hive_nn_conv72
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, packed=None, packed_t=None, link=None):
+        """packed / packed_t: this weight already in the kernels' layout (forward / data-gradient form), as
+        FusedTrainNet packs all tower convolutions of a step in one launch; None: packed here.  link: see _BNAct."""
         from . import _lib
         L = _lib.load()
         if x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
@@ -222,11 +235,16 @@ class _Conv3x3(torch.autograd.Function):
         B, cin = x.shape[0], x.shape[1]
         dev = x.device
         cinp = (cin + 63) // 64 * 64
-        wp = torch.empty(9 * cinp * 256, dtype=torch.bfloat16, device=dev)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-        wsrc, wcl = _weight_layout(weight)
-        _lib.check(L.hive_nn_pack_conv3x3_weights(p(wsrc), cin, 0, wcl, p(wp), st))
+        if packed is not None:
+            wp = packed
+        else:
+            wp = torch.empty(9 * cinp * 256, dtype=torch.bfloat16, device=dev)
+            wsrc, wcl = _weight_layout(weight)
+            _lib.check(L.hive_nn_pack_conv3x3_weights(p(wsrc), cin, 0, wcl, p(wp), st))
+        ctx.packed_t = packed_t
+        ctx.link = link
         b = bias if bias is not None else _const("zero_bias", 0, dev)
         y = torch.empty((B, 256, 12, 12), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
         if cin == 256 and _Conv3x3.asm_conv:         # the 72-tile assembly kernel (two boards per workgroup): same bits
@@ -250,23 +268,39 @@ class _Conv3x3(torch.autograd.Function):
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         dx = None
         if ctx.needs_input_grad[0]:
-            wt = torch.empty(9 * 256 * 256, dtype=torch.bfloat16, device=dev)
-            wsrc, wcl = _weight_layout(weight)
-            _lib.check(L.hive_nn_pack_conv3x3_weights(p(wsrc), cin, 1, wcl, p(wt), st))
-            dx = torch.empty_like(x)
-            if cin == 256 and _Conv3x3.asm_conv:
-                _lib.check(L.hive_nn_conv72(p(dy), p(wt), p(_const("zero_bias", 0, dev)), p(dx), B, 0, _lib.BF16, st))
+            wt = ctx.packed_t
+            if wt is None:
+                wt = torch.empty(9 * 256 * 256, dtype=torch.bfloat16, device=dev)
+                wsrc, wcl = _weight_layout(weight)
+                _lib.check(L.hive_nn_pack_conv3x3_weights(p(wsrc), cin, 1, wcl, p(wt), st))
+            extra = ctx.link.pop("dres", None) if ctx.link is not None else None      # the skip gradient of the same input
+            if extra is not None and cin == 256 and _Conv3x3.asm_conv:
+                dx = extra                                  # dx = dgrad(dy) + dskip, summed in fp32, written over dskip
+                _lib.check(L.hive_nn_conv72_add(p(dy), p(wt), p(_const("zero_bias", 0, dev)), p(extra), p(dx), B, 0, _lib.BF16, st))
+                extra = None
             else:
-                _lib.check(L.hive_nn_conv3x3(p(dy), 256, p(wt), p(_const("zero_bias", 0, dev)), None, p(dx), B, 0, st))
+                dx = torch.empty_like(x)
+                if cin == 256 and _Conv3x3.asm_conv:
+                    _lib.check(L.hive_nn_conv72(p(dy), p(wt), p(_const("zero_bias", 0, dev)), p(dx), B, 0, _lib.BF16, st))
+                else:
+                    _lib.check(L.hive_nn_conv3x3(p(dy), 256, p(wt), p(_const("zero_bias", 0, dev)), None, p(dx), B, 0, st))
+            if extra is not None:
+                dx = dx + extra
         if cin == 256 and _Conv3x3.hip_wgrad:
-            taps = torch.empty((3, 3, 256, 256), dtype=torch.float32, device=dev)
-            _lib.check(L.hive_nn_conv3x3_wgrad(p(x), p(dy), p(taps), B, p(_wgrad_workspace(L, dev)), st))
-            dw = taps.permute(2, 3, 0, 1)                      # [k][c][ty][tx], the strides torch.channels_last gives a weight
+            if weight.is_contiguous(memory_format=torch.channels_last) and not weight.is_contiguous():
+                # the gradient in the parameter's own memory order [k][ty][tx][c]: autograd keeps it as it is (a gradient with
+                # other strides is copied into the parameter's layout when it is accumulated: 38 strided copies per step)
+                dw = torch.empty_strided((256, 256, 3, 3), weight.stride(), dtype=torch.float32, device=dev)
+                _lib.check(L.hive_nn_conv3x3_wgrad_layout(p(x), p(dy), p(dw), B, p(_wgrad_workspace(L, dev)), 1, st))
+            else:
+                taps = torch.empty((3, 3, 256, 256), dtype=torch.float32, device=dev)
+                _lib.check(L.hive_nn_conv3x3_wgrad(p(x), p(dy), p(taps), B, p(_wgrad_workspace(L, dev)), st))
+                dw = taps.permute(2, 3, 0, 1)                  # [k][c][ty][tx] as a view of [ty][tx][k][c]
         else:
             dw = torch.ops.aten.convolution_backward(dy, x, _const("weight_like", cin, dev), None, (1, 1), (1, 1), (1, 1), False,
                                                      (0, 0), 1, (False, True, False))[1].float()
         db = dy.float().sum(dim=(0, 2, 3)) if ctx.has_bias else None
-        return dx, dw, db
+        return dx, dw, db, None, None, None
 
 
 def _wgrad_workspace(L, dev):
@@ -286,14 +320,22 @@ def _weight_layout(w):
     return w.contiguous(), 0
 
 
-def conv3x3(x, conv):
+def conv3x3(x, conv, packed=None, packed_t=None, link=None):
     """conv(x) for a 3x3 / stride 1 / padding 1 nn.Conv2d with 256 output channels, through the HIP kernel."""
-    return _Conv3x3.apply(x, conv.weight, conv.bias)
+    return _Conv3x3.apply(x, conv.weight, conv.bias, packed, packed_t, link)
 
 
-def bn_act(x, bn, residual=None, relu=True):
-    """relu(bn(x) + residual) in training mode through the HIP kernels (updates bn's running statistics)."""
-    return _BNAct.apply(x, bn.weight, bn.bias, residual, bn, relu)
+def bn_act_ok(x):
+    """Whether the HIP BatchNorm kernels take this [B, C, H, W] activation: C a power of two <= 256 and the
+    [B*H*W][C] matrix a whole number of 256-wide rows (include/hive_nn.h)."""
+    C = x.shape[1]
+    return x.is_cuda and 1 <= C <= 256 and (C & (C - 1)) == 0 and (x.shape[0] * x.shape[2] * x.shape[3] * C) % 256 == 0
+
+
+def bn_act(x, bn, residual=None, relu=True, track=True, link=None):
+    """relu(bn(x) + residual) in training mode through the HIP kernels (updates bn's running statistics; track=False
+    leaves num_batches_tracked to the caller, who can bump all layers' counters in one launch; link: see _BNAct)."""
+    return _BNAct.apply(x, bn.weight, bn.bias, residual, bn, relu, track, link)
 
 
 class FusedTrainNet(nn.Module):
@@ -301,22 +343,78 @@ class FusedTrainNet(nn.Module):
     state_dict see the reference's network), but every BatchNorm + skip + ReLU of the 256-channel tower is one fused
     HIP forward / backward (alpha_net.py:25-54); the two heads stay on the library path."""
 
+    pack_once = True         # the 38 tower convolutions' weights packed by ONE launch per step (both forms)
+    hip_head_bn = True       # the heads' BatchNorm2d(1) / BatchNorm2d(128) + ReLU on the HIP kernels too
+    fuse_skip_grad = True    # a block input's two gradients (conv1's data gradient + the skip's) summed in the convolution launch
+
     def __init__(self, net, hip_conv=True):
         super().__init__()
         self.net = net
         self.hip_conv = hip_conv
+        self._pack = None        # (data_ptr tuple, device pointer table, forward-form buffer, data-gradient-form buffer)
+
+    def _packed_tower(self, dev):
+        """[38][589824] bf16 twice: every ResBlock convolution's weight in the forward and the data-gradient form of
+        hive_nn_conv3x3 / hive_nn_conv72 (hive_nn_pack_conv3x3_weights_multi).  The buffers are reused step after step: a
+        step's backward has run on this stream before the next forward packs again."""
+        from . import _lib
+        L = _lib.load()
+        ws = []
+        for i in range(19):
+            blk = getattr(self.net, "res_%i" % i)
+            ws += [blk.conv1.weight, blk.conv2.weight]
+        lay = [_weight_layout(w) for w in ws]
+        if any(t is not w for (t, _), w in zip(lay, ws)) or len({cl for _, cl in lay}) != 1:
+            return None                                    # mixed or strided storage: each convolution packs its own
+        ptrs = tuple(w.data_ptr() for w in ws)
+        if self._pack is None or self._pack[0] != ptrs or self._pack[1].device != dev:
+            table = torch.tensor(ptrs, dtype=torch.int64).to(dev)
+            fwd = torch.empty((len(ws), 9 * 256 * 256), dtype=torch.bfloat16, device=dev)
+            self._pack = (ptrs, table, fwd, torch.empty_like(fwd))
+        _, table, fwd, bwd = self._pack
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(L.hive_nn_pack_conv3x3_weights_multi(ctypes.c_void_p(table.data_ptr()), len(ws), lay[0][1],
+                                                        ctypes.c_void_p(fwd.data_ptr()), ctypes.c_void_p(bwd.data_ptr()), st))
+        return fwd, bwd
 
     def forward(self, s):
         net = self.net
         if not (net.training and s.is_cuda):      # eval mode (running statistics) and CPU runs use the modules as they are
             return net(s)
-        conv = conv3x3 if self.hip_conv else (lambda t, m: m(t))
-        s = bn_act(conv(s, net.conv.conv1), net.conv.bn1)
+        if not self.hip_conv:
+            conv = lambda t, m, *a, **k: m(t)
+            packed = None
+        else:
+            conv = conv3x3
+            packed = self._packed_tower(s.device) if self.pack_once else None
+        pk = (lambda j: (packed[0][j], packed[1][j])) if packed is not None else (lambda j: (None, None))
+        s = bn_act(conv(s, net.conv.conv1), net.conv.bn1, track=False)
+        counters = [net.conv.bn1.num_batches_tracked]
         for i in range(19):
             blk = getattr(net, "res_%i" % i)
-            out = bn_act(conv(s, blk.conv1), blk.bn1)
-            s = bn_act(conv(out, blk.conv2), blk.bn2, residual=s)
-        return net.outblock(s)
+            # the block's input feeds conv1 and the skip connection: its two gradients are summed inside conv1's data-gradient
+            # launch (hive_nn_conv72_add) when the two operators are linked
+            link = {} if (self.fuse_skip_grad and self.hip_conv and s.requires_grad) else None
+            out = bn_act(conv(s, blk.conv1, *pk(2 * i), link=link), blk.bn1, track=False)
+            s = bn_act(conv(out, blk.conv2, *pk(2 * i + 1)), blk.bn2, residual=s, track=False, link=link)
+            counters += [blk.bn1.num_batches_tracked, blk.bn2.num_batches_tracked]
+        out, hb = net.outblock, self.hip_head_bn
+        v = out.conv(s)                            # OutBlock.forward (alpha_net.py:67-80) with the two BatchNorms on the HIP kernels
+        pl = out.conv1(s)
+        if hb and bn_act_ok(v) and bn_act_ok(pl):
+            v = bn_act(v, out.bn, track=False)
+            pl = bn_act(pl, out.bn1, track=False)
+            counters += [out.bn.num_batches_tracked, out.bn1.num_batches_tracked]
+        else:
+            v = F.relu(out.bn(v))
+            pl = F.relu(out.bn1(pl))
+        torch._foreach_add_(counters, 1)          # nn.BatchNorm2d's num_batches_tracked += 1, all layers in one launch
+        v = v.reshape(-1, MAX_MAP_FULL * MAX_MAP_FULL)
+        v = F.relu(out.fc1(v))
+        v = torch.tanh(out.fc2(v))
+        pl = pl.reshape(-1, MAX_MAP_FULL * MAX_MAP_FULL * 128)
+        pl = out.fc(pl)
+        return out.logsoftmax(pl).exp(), v
 
 
 class Trainer:

@@ -82,13 +82,17 @@ S_D = 56                      # 8: this workgroup's plan entry: head pair, head 
                               #    pairs, tail pair, tail first block, -, -
 S_PHASE, S_PAIR, S_B0, S_B1, S_MODE, S_POLL = 64, 65, 66, 67, 68, 69
 S_FLAG = 70                   # pair: address of the current pair's hand-over flag
-S_FLAGS = 76                  # kernarg flags: bit 0 = ONE convolution per block (conv + bias [+ ReLU] -> y), bit 1 = no ReLU
+S_FLAGS = 76                  # kernarg flags: bit 0 = ONE convolution per block (conv + bias [+ ReLU] -> y), bit 1 = no ReLU,
+                              # bit 2 (with bit 0) = ... + residual: the convolution runs as a block's SECOND one, whose epilogue adds a
+                              # skip operand -- here the rows of the kernarg `residual` instead of the block's input
+S_RES = 78                    # pair: kernarg residual (flags bit 2)
 S_STG0, S_STG1 = 72, 74       # pairs: where the current segment's boards are staged from (X rows, or Y rows for a tail)
 PLAN_STRIDE = 32              # bytes per workgroup in the plan
 MAX_WG = 256                  # workgroups a plan covers; the flags start at plan + MAX_WG * PLAN_STRIDE
 BLOCK_W_BYTES = 2 * 72 * KSTEP_BYTES     # packed weights of one residual block
 S_HAS1 = 48                   # pair: exec mask for the second board's global stores (0 when the pair's second entry repeats the first)
 NEXT_SGPR = 80
+assert S_RES + 2 <= NEXT_SGPR
 
 
 def acc_reg(t):
@@ -187,11 +191,12 @@ def gen_kernel(name, dt, debug=0):
     e, c = A.e, A.comment
 
     # =============================================================== prologue
-    c("kernarg: X W bias Y idx count | batch nblocks | plan | flags")
+    c("kernarg: X W bias Y idx count | batch nblocks | plan | flags | residual")
     e("s_load_dwordx8 %s, %s, 0x0" % (sr(S_X, 8), sr(S_KARG, 2)))
     e("s_load_dwordx4 %s, %s, 0x20" % (sr(S_IDX, 4), sr(S_KARG, 2)))
     e("s_load_dwordx4 %s, %s, 0x30" % (sr(S_N, 4), sr(S_KARG, 2)))
     e("s_load_dword %s, %s, 0x40" % (sr(S_FLAGS), sr(S_KARG, 2)))
+    e("s_load_dwordx2 %s, %s, 0x48" % (sr(S_RES, 2), sr(S_KARG, 2)))
     e("v_lshrrev_b32_e32 %s, 6, %s" % (vr(V_TMP), vr(V_TID)))
     e("s_nop 1")                                 # (a VALU-written register is not yet visible to v_readfirstlane)
     e("v_readfirstlane_b32 %s, %s" % (sr(S_WAVE), vr(V_TMP)))
@@ -365,6 +370,15 @@ def gen_kernel(name, dt, debug=0):
     A.label(".L%s_fromx" % name)
     e("s_mov_b64 %s, %s" % (sr(S_STG0, 2), sr(S_SKIP0, 2)))
     e("s_mov_b64 %s, %s" % (sr(S_STG1, 2), sr(S_SKIP1, 2)))
+    c("flags bit 2: the skip operand of the (one) convolution = the same rows of `residual`")
+    e("s_bitcmp1_b32 %s, 2" % sr(S_FLAGS))
+    e("s_cbranch_scc0 .L%s_nores" % name)
+    for skip, stg in ((S_SKIP0, S_STG0), (S_SKIP1, S_STG1)):
+        e("s_sub_u32 %s, %s, %s" % (sr(S_T1), sr(stg), sr(S_X)))
+        e("s_subb_u32 %s, %s, %s" % (sr(S_T2), sr(stg + 1), sr(S_X + 1)))
+        e("s_add_u32 %s, %s, %s" % (sr(skip), sr(S_RES), sr(S_T1)))
+        e("s_addc_u32 %s, %s, %s" % (sr(skip + 1), sr(S_RES + 1), sr(S_T2)))
+    A.label(".L%s_nores" % name)
     c("this segment's blocks: weights, biases, counters")
     e("s_mul_i32 %s, %s, 0x%x" % (sr(S_T1), sr(S_B0), BLOCK_W_BYTES))
     e("s_mul_hi_u32 %s, %s, 0x%x" % (sr(S_T2), sr(S_B0), BLOCK_W_BYTES))
@@ -373,6 +387,10 @@ def gen_kernel(name, dt, debug=0):
     e("s_lshl_b32 %s, %s, 11" % (sr(S_T1), sr(S_B0)))
     e("s_add_u32 %s, %s, %s" % (sr(S_BP), sr(S_BIAS), sr(S_T1)))
     e("s_addc_u32 %s, %s, 0" % (sr(S_BP + 1), sr(S_BIAS + 1)))
+    e("s_bitcmp1_b32 %s, 2" % sr(S_FLAGS))               # (the second convolution's epilogue reads its bias 1 KiB further on)
+    e("s_cselect_b32 %s, 0x400, 0" % sr(S_T1))
+    e("s_sub_u32 %s, %s, %s" % (sr(S_BP), sr(S_BP), sr(S_T1)))
+    e("s_subb_u32 %s, %s, 0" % (sr(S_BP + 1), sr(S_BP + 1)))
     e("s_sub_u32 %s, %s, %s" % (sr(S_BLK), sr(S_B1), sr(S_B0)))
     e("s_sub_u32 %s, %s, %s" % (sr(S_WLEFT), sr(S_NBLK), sr(S_B0)))
     e("s_mul_i32 %s, %s, 144" % (sr(S_WLEFT), sr(S_WLEFT)))
@@ -647,6 +665,9 @@ def gen_kernel(name, dt, debug=0):
 
     A.label(".L%s_block" % name)
     stamp(0)
+    c("flags bit 2: one convolution WITH a residual = the second convolution's code on the staged boards and the first weights")
+    e("s_bitcmp1_b32 %s, 2" % sr(S_FLAGS))
+    e("s_cbranch_scc1 .L%s_twoconv" % name)
     if debug == 2:
         c("DEBUG 2: no convolutions -- epilogue 2 on zero accumulators: y = relu(b2 + x)")
         e("s_branch .L%s_epi2" % name)
@@ -823,7 +844,7 @@ def kernel_text(name, dt, debug=0):
     out += ["\t.section\t.rodata,\"a\",@progbits", "\t.p2align\t6, 0x0", "\t.amdhsa_kernel %s" % name,
             "\t\t.amdhsa_group_segment_fixed_size %d" % LDS_BYTES,
             "\t\t.amdhsa_private_segment_fixed_size 0",
-            "\t\t.amdhsa_kernarg_size 72",
+            "\t\t.amdhsa_kernarg_size 80",
             "\t\t.amdhsa_user_sgpr_count 2",
             "\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1",
             "\t\t.amdhsa_system_sgpr_workgroup_id_x 1",
@@ -856,7 +877,9 @@ def metadata(names):
         out += ["      - .address_space:  global", "        .offset:         56", "        .size:           8",
                 "        .value_kind:     global_buffer"]
         out += ["      - .offset:         64", "        .size:           4", "        .value_kind:     by_value"]
-        out += ["    .group_segment_fixed_size: %d" % LDS_BYTES, "    .kernarg_segment_align: 8", "    .kernarg_segment_size: 72",
+        out += ["      - .address_space:  global", "        .offset:         72", "        .size:           8",
+                "        .value_kind:     global_buffer"]
+        out += ["    .group_segment_fixed_size: %d" % LDS_BYTES, "    .kernarg_segment_align: 8", "    .kernarg_segment_size: 80",
                 "    .max_flat_workgroup_size: 256", "    .name:           %s" % name, "    .private_segment_fixed_size: 0",
                 "    .sgpr_count:     %d" % (NEXT_SGPR + 6), "    .sgpr_spill_count: 0", "    .symbol:         %s.kd" % name,
                 "    .uniform_work_group_size: 1", "    .uses_dynamic_stack: false", "    .vgpr_count:     %d" % (NEXT_VGPR + 256),

@@ -633,8 +633,9 @@ struct Tower72Args {
     int32_t batch, nblocks;
     const int32_t *plan;
     int32_t flags, pad;
+    const void *residual;
 };
-static_assert(sizeof(Tower72Args) == 72, "kernarg layout of hive_tower72_* (gen_tower_asm.py)");
+static_assert(sizeof(Tower72Args) == 80, "kernarg layout of hive_tower72_* (gen_tower_asm.py)");
 constexpr int kPlanMaxWg = 256, kPlanStride = 8;      // MAX_WG, PLAN_STRIDE / 4 of gen_tower_asm.py
 
 // The launch plan of a balanced tower: `grid` workgroups (one per CU, all resident) share pairs * nblocks block-steps evenly.
@@ -744,7 +745,8 @@ extern "C" long long hive_nn_tower72_plan_bytes(int batch)
 }
 
 static int tower72_launch(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
-                          const int32_t *rows, const int32_t *nrows, int32_t *plan, void *stream, int flags = 0);
+                          const int32_t *rows, const int32_t *nrows, int32_t *plan, void *stream, int flags = 0,
+                          const void *residual = nullptr);
 
 extern "C" int hive_nn_tower72(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
                                const int32_t *rows, const int32_t *nrows, void *stream)
@@ -767,8 +769,18 @@ extern "C" int hive_nn_conv72(const void *x, const void *w, const float *bias, v
     return tower72_launch(x, w, bias, y, batch, 1, dtype, nullptr, nullptr, nullptr, stream, 1 | (relu ? 0 : 2));
 }
 
+extern "C" int hive_nn_conv72_add(const void *x, const void *w, const float *bias, const void *residual, void *y, int batch, int relu,
+                                  int dtype, void *stream)
+{
+    // ... + residual (flags bit 2): the convolution runs as the kernel's SECOND convolution of a block, whose epilogue adds a skip
+    // operand in fp32 before the one rounding -- here the rows of `residual` (it may be y itself: a workgroup has read its two
+    // rows of the residual before it stores them)
+    if (!residual) return set_error(HIVE_E_ARG, "hive_nn_conv72_add: residual == NULL");
+    return tower72_launch(x, w, bias, y, batch, 1, dtype, nullptr, nullptr, nullptr, stream, 1 | (relu ? 0 : 2) | 4, residual);
+}
+
 static int tower72_launch(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
-                          const int32_t *rows, const int32_t *nrows, int32_t *plan, void *stream, int flags)
+                          const int32_t *rows, const int32_t *nrows, int32_t *plan, void *stream, int flags, const void *residual)
 {
     if (!x || !w || !bias || !y || batch <= 0 || nblocks <= 0 || x == y)
         return set_error(HIVE_E_ARG, "hive_nn_tower72: bad argument (y must not alias x)");
@@ -793,7 +805,7 @@ static int tower72_launch(const void *x, const void *w, const float *bias, void 
         hipLaunchKernelGGL(tower72_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nrows, batch, nblocks, (int)grid, plan,
                            (batch + 1) / 2);
     }
-    Tower72Args args{x, w, bias, y, rows, nrows, batch, nblocks, plan, flags, 0};
+    Tower72Args args{x, w, bias, y, rows, nrows, batch, nblocks, plan, flags, 0, residual};
     size_t size = sizeof(args);
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     hipError_t e = hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, config);

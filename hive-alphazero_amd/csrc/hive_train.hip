@@ -45,9 +45,13 @@ __device__ __forceinline__ void store8(__bf16 *p, const float (&v)[8])
 }
 
 // Reduce the 8 row lanes of a workgroup and write its partial sums: partial[wg][0..255] = a, [256..511] = b.
-__device__ __forceinline__ void reduce_rows(float (&a)[8], float (&b)[8], float *partial_wg)
+// C < 256 channels (the heads' BatchNorm2d(128) / (1): a [positions][C] matrix read as [positions * C / 256][256], so
+// columns j, j + C, j + 2C, ... are the same channel): the columns of a channel are added up here and only entries
+// 0 .. C-1 of each half are written.
+__device__ __forceinline__ void reduce_rows(float (&a)[8], float (&b)[8], float *partial_wg, int C)
 {
     __shared__ float red[8][2 * kBnC];
+    __shared__ float col[2 * kBnC];
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -55,18 +59,33 @@ __device__ __forceinline__ void reduce_rows(float (&a)[8], float (&b)[8], float 
         red[rl][kBnC + cg * 8 + i] = b[i];
     }
     __syncthreads();
+    if (C == kBnC) {
+        for (int j = threadIdx.x; j < 2 * kBnC; j += kBnThreads) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += red[r][j];
+            partial_wg[j] = s;
+        }
+        return;
+    }
     for (int j = threadIdx.x; j < 2 * kBnC; j += kBnThreads) {
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) s += red[r][j];
-        partial_wg[j] = s;
+        col[j] = s;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * C; j += kBnThreads) {
+        const int half = j / C, c = j - half * C;
+        float s = 0.f;
+        for (int m = c; m < kBnC; m += C) s += col[half * kBnC + m];
+        partial_wg[half * kBnC + c] = s;
     }
 }
 
 // Finish kernels: 32 workgroups x 256 threads, workgroup w owns channels 8 w .. 8 w + 7; thread (k, j) adds the
 // partials of streaming workgroups k, k+32, ... for channel c = 8 w + j (16 independent loads per array); the threads
 // with k == 0 return true with the two totals of their channel.
-constexpr int kFinishGrid = kBnC / 8;
 __device__ __forceinline__ bool sum_partials(const float *partial, int grid, int &c, float &a, float &b)
 {
     __shared__ float tot[32][16];
@@ -90,7 +109,7 @@ __device__ __forceinline__ bool sum_partials(const float *partial, int grid, int
 
 // ---------------------------------------------------------------- forward
 __global__ void __launch_bounds__(kBnThreads)
-bn_fwd_stats_kernel(const __bf16 *__restrict__ x, long long rows, float *__restrict__ partial)
+bn_fwd_stats_kernel(const __bf16 *__restrict__ x, long long rows, float *__restrict__ partial, int C)
 {
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -101,7 +120,7 @@ bn_fwd_stats_kernel(const __bf16 *__restrict__ x, long long rows, float *__restr
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s[i] += v[i]; q[i] += v[i] * v[i]; }
     }
-    reduce_rows(s, q, partial + (long long)blockIdx.x * 2 * kBnC);
+    reduce_rows(s, q, partial + (long long)blockIdx.x * 2 * kBnC, C);
 }
 
 // coef[0..255] = scale, [256..511] = shift
@@ -109,12 +128,12 @@ __global__ void __launch_bounds__(kBnThreads)
 bn_fwd_finish_kernel(const float *__restrict__ partial, int grid, long long rows, const float *__restrict__ gamma,
                      const float *__restrict__ beta, float *__restrict__ running_mean, float *__restrict__ running_var,
                      float momentum, float eps, float *__restrict__ save_mean, float *__restrict__ save_invstd,
-                     float *__restrict__ coef)
+                     float *__restrict__ coef, int C)
 {
     float s, q;
     int c;
-    if (!sum_partials(partial, grid, c, s, q)) return;
-    const float n = (float)rows;
+    if (!sum_partials(partial, grid, c, s, q) || c >= C) return;
+    const float n = (float)rows * (float)(kBnC / C);            // values per channel
     const float mean = s / n;
     const float var = fmaxf(q / n - mean * mean, 0.f);          // biased, as BatchNorm normalises with it
     const float invstd = rsqrtf(var + eps);
@@ -132,12 +151,18 @@ bn_fwd_finish_kernel(const float *__restrict__ partial, int grid, long long rows
 template <bool RES>
 __global__ void __launch_bounds__(kBnThreads)
 bn_fwd_apply_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ res, const float *__restrict__ coef,
-                    long long rows, int relu, __bf16 *__restrict__ y)
+                    long long rows, int relu, __bf16 *__restrict__ y, int cmask)
 {
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
     float sc[8], sh[8];
+    const int c0 = (cg * 8) & cmask;            // 8 consecutive channels (two 16-byte loads per array) unless C < 8
+    if (cmask >= 7) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { sc[i] = coef[cg * 8 + i]; sh[i] = coef[kBnC + cg * 8 + i]; }
+        for (int i = 0; i < 8; ++i) { sc[i] = coef[c0 + i]; sh[i] = coef[kBnC + c0 + i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sc[i] = coef[i & cmask]; sh[i] = coef[kBnC + (i & cmask)]; }
+    }
 #pragma unroll 4
     for (long long r = (long long)blockIdx.x * 8 + rl; r < rows; r += (long long)gridDim.x * 8) {
         const long long o = r * kBnC + cg * 8;
@@ -163,12 +188,19 @@ bn_fwd_apply_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ res
 __global__ void __launch_bounds__(kBnThreads)
 bn_bwd_stats_kernel(const __bf16 *__restrict__ dy, const __bf16 *__restrict__ y, const __bf16 *__restrict__ x,
                     const float *__restrict__ save_mean, const float *__restrict__ save_invstd, long long rows, int relu,
-                    float *__restrict__ partial)
+                    float *__restrict__ partial, int C)
 {
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int cmask = C - 1;
     float mu[8], is[8];
+    const int c0 = (cg * 8) & cmask;
+    if (cmask >= 7) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { mu[i] = save_mean[cg * 8 + i]; is[i] = save_invstd[cg * 8 + i]; }
+        for (int i = 0; i < 8; ++i) { mu[i] = save_mean[c0 + i]; is[i] = save_invstd[c0 + i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { mu[i] = save_mean[i & cmask]; is[i] = save_invstd[i & cmask]; }
+    }
     float db[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 4
     for (long long r = (long long)blockIdx.x * 8 + rl; r < rows; r += (long long)gridDim.x * 8) {
@@ -185,21 +217,21 @@ bn_bwd_stats_kernel(const __bf16 *__restrict__ dy, const __bf16 *__restrict__ y,
 #pragma unroll
         for (int i = 0; i < 8; ++i) { db[i] += g[i]; dg[i] += g[i] * (xv[i] - mu[i]) * is[i]; }
     }
-    reduce_rows(db, dg, partial + (long long)blockIdx.x * 2 * kBnC);
+    reduce_rows(db, dg, partial + (long long)blockIdx.x * 2 * kBnC, C);
 }
 
 // coef[0..255] = gamma/std, [256..511] = dbeta/N, [512..767] = dgamma/N
 __global__ void __launch_bounds__(kBnThreads)
 bn_bwd_finish_kernel(const float *__restrict__ partial, int grid, long long rows, const float *__restrict__ gamma,
                      const float *__restrict__ save_invstd, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                     float *__restrict__ coef)
+                     float *__restrict__ coef, int C)
 {
     float b, g;
     int c;
-    if (!sum_partials(partial, grid, c, b, g)) return;
+    if (!sum_partials(partial, grid, c, b, g) || c >= C) return;
     dbeta[c] = b;
     dgamma[c] = g;
-    const float n = (float)rows;
+    const float n = (float)rows * (float)(kBnC / C);
     coef[c] = gamma[c] * save_invstd[c];
     coef[kBnC + c] = b / n;
     coef[2 * kBnC + c] = g / n;
@@ -210,17 +242,30 @@ __global__ void __launch_bounds__(kBnThreads)
 bn_bwd_apply_kernel(const __bf16 *__restrict__ dy, const __bf16 *__restrict__ y, const __bf16 *__restrict__ x,
                     const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
                     const float *__restrict__ coef, long long rows, int relu, __bf16 *__restrict__ dx,
-                    __bf16 *__restrict__ dres)
+                    __bf16 *__restrict__ dres, int cmask)
 {
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
     float mu[8], is[8], a[8], cb[8], cgm[8];
+    const int c0 = (cg * 8) & cmask;
+    if (cmask >= 7) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        mu[i] = save_mean[cg * 8 + i];
-        is[i] = save_invstd[cg * 8 + i];
-        a[i] = coef[cg * 8 + i];
-        cb[i] = coef[kBnC + cg * 8 + i];
-        cgm[i] = coef[2 * kBnC + cg * 8 + i];
+        for (int i = 0; i < 8; ++i) {
+            mu[i] = save_mean[c0 + i];
+            is[i] = save_invstd[c0 + i];
+            a[i] = coef[c0 + i];
+            cb[i] = coef[kBnC + c0 + i];
+            cgm[i] = coef[2 * kBnC + c0 + i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = i & cmask;
+            mu[i] = save_mean[c];
+            is[i] = save_invstd[c];
+            a[i] = coef[c];
+            cb[i] = coef[kBnC + c];
+            cgm[i] = coef[2 * kBnC + c];
+        }
     }
 #pragma unroll 4
     for (long long r = (long long)blockIdx.x * 8 + rl; r < rows; r += (long long)gridDim.x * 8) {
@@ -272,9 +317,48 @@ pack_weights_kernel(const float *__restrict__ w, int cin, int cinp, int transpos
     *reinterpret_cast<bf16x8 *>(out + (long long)idx * 8) = v;
 }
 
+// All 256 -> 256 convolutions of a training step at once: blockIdx.y = 2 * layer + form (0 forward, 1 data gradient); one launch
+// instead of one per convolution and direction (77 launches x 5.6 us of a 15 ms step).
+__global__ void __launch_bounds__(256)
+pack_weights_multi_kernel(const float *const *__restrict__ ws, int channels_last, __bf16 *__restrict__ out_fwd,
+                          __bf16 *__restrict__ out_t)
+{
+    constexpr int cin = 256, ks_n = 8;
+    const int layer = blockIdx.y >> 1, transpose = blockIdx.y & 1;
+    const float *__restrict__ w = ws[layer];
+    __bf16 *out = (transpose ? out_t : out_fwd) + (long long)layer * 9 * 256 * 256;
+    const int idx = blockIdx.x * 256 + threadIdx.x;              // one 8-channel vector of the output
+    if (idx >= 9 * ks_n * 16 * 4 * 16) return;
+    const int row = idx & 15, kg = (idx >> 4) & 3, mt = (idx >> 6) & 15, rest = idx >> 10;
+    const int ks = rest % ks_n, tap = rest / ks_n;
+    const int m = mt * 16 + row, c0 = ks * 32 + kg * 8;
+    const int wt = transpose ? 8 - tap : tap;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        const int ko = transpose ? c : m, ki = transpose ? m : c;
+        v[e] = (__bf16)(channels_last ? w[((long long)ko * 9 + wt) * cin + ki] : w[((long long)ko * cin + ki) * 9 + wt]);
+    }
+    *reinterpret_cast<bf16x8 *>(out + (long long)idx * 8) = v;
+}
+
 }  // namespace hive
 
 using namespace hive;
+
+extern "C" int hive_nn_pack_conv3x3_weights_multi(const float *const *weights, int n, int channels_last, void *out_fwd,
+                                                  void *out_t, void *stream)
+{
+    if (!weights || !out_fwd || !out_t || n <= 0 || n > 32767)
+        return set_error(HIVE_E_ARG, "hive_nn_pack_conv3x3_weights_multi: bad argument");
+    const int vecs = 9 * 8 * 16 * 4 * 16;
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)(vecs / 256), (unsigned)(2 * n)), dim3(256), 0, (hipStream_t)stream,
+                       weights, channels_last, (__bf16 *)out_fwd, (__bf16 *)out_t);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(HIVE_E_DEVICE, std::string("hive_nn_pack_conv3x3_weights_multi: ") + hipGetErrorString(e));
+    return HIVE_OK;
+}
 
 extern "C" int hive_nn_pack_conv3x3_weights(const float *w, int cin, int transpose, int channels_last, void *out,
                                             void *stream)
@@ -296,6 +380,13 @@ extern "C" int hive_nn_pack_conv3x3_weights(const float *w, int cin, int transpo
         if (e_ != hipSuccess) return set_error(HIVE_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// channels: a power of two <= 256 whose [positions][channels] matrix is a whole number of 256-wide rows
+static bool bn_shape_ok(long long rows, int channels)
+{
+    return channels >= 1 && channels <= kBnC && (channels & (channels - 1)) == 0 && (rows * channels) % kBnC == 0;
+}
+static const char *kBnShapeMsg = "hive_nn_bn_act: channels must be a power of two <= 256 and rows * channels a multiple of 256";
+
 extern "C" int hive_nn_bn_workspace_floats(void) { return kBnGrid * 2 * kBnC + 3 * kBnC; }
 
 extern "C" int hive_nn_bn_act_fwd(const void *x, const void *residual, const float *gamma, const float *beta,
@@ -305,18 +396,21 @@ extern "C" int hive_nn_bn_act_fwd(const void *x, const void *residual, const flo
 {
     if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !workspace || rows <= 0)
         return set_error(HIVE_E_ARG, "hive_nn_bn_act_fwd: bad argument");
-    if (channels != kBnC) return set_error(HIVE_E_ARG, "hive_nn_bn_act_fwd: channels must be 256");
+    if (!bn_shape_ok(rows, channels)) return set_error(HIVE_E_ARG, kBnShapeMsg);
     if ((running_mean == nullptr) != (running_var == nullptr))
         return set_error(HIVE_E_ARG, "hive_nn_bn_act_fwd: running_mean and running_var go together");
     hipStream_t s = (hipStream_t)stream;
+    const int C = channels;
+    rows = rows * C / kBnC;                                     // the matrix as [rows][256]
     const int grid = (int)((rows + 7) / 8 < kBnGrid ? (rows + 7) / 8 : kBnGrid);
+    const int fgrid = C >= 8 ? C / 8 : 1;
     float *partial = workspace, *coef = workspace + (long long)kBnGrid * 2 * kBnC;
     const __bf16 *X = (const __bf16 *)x, *R = (const __bf16 *)residual;
-    hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(grid), dim3(kBnThreads), 0, s, X, rows, partial);
-    hipLaunchKernelGGL(bn_fwd_finish_kernel, dim3(kFinishGrid), dim3(kBnThreads), 0, s, partial, grid, rows, gamma, beta, running_mean,
-                       running_var, momentum, eps, save_mean, save_invstd, coef);
-    if (R) hipLaunchKernelGGL((bn_fwd_apply_kernel<true>), dim3(grid), dim3(kBnThreads), 0, s, X, R, coef, rows, relu, (__bf16 *)y);
-    else hipLaunchKernelGGL((bn_fwd_apply_kernel<false>), dim3(grid), dim3(kBnThreads), 0, s, X, R, coef, rows, relu, (__bf16 *)y);
+    hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(grid), dim3(kBnThreads), 0, s, X, rows, partial, C);
+    hipLaunchKernelGGL(bn_fwd_finish_kernel, dim3(fgrid), dim3(kBnThreads), 0, s, partial, grid, rows, gamma, beta, running_mean,
+                       running_var, momentum, eps, save_mean, save_invstd, coef, C);
+    if (R) hipLaunchKernelGGL((bn_fwd_apply_kernel<true>), dim3(grid), dim3(kBnThreads), 0, s, X, R, coef, rows, relu, (__bf16 *)y, C - 1);
+    else hipLaunchKernelGGL((bn_fwd_apply_kernel<false>), dim3(grid), dim3(kBnThreads), 0, s, X, R, coef, rows, relu, (__bf16 *)y, C - 1);
     BN_TRY(hipGetLastError());
     return HIVE_OK;
 }
@@ -328,21 +422,24 @@ extern "C" int hive_nn_bn_act_bwd(const void *dy, const void *x, const void *y, 
     if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 ||
         (relu && !y))
         return set_error(HIVE_E_ARG, "hive_nn_bn_act_bwd: bad argument");
-    if (channels != kBnC) return set_error(HIVE_E_ARG, "hive_nn_bn_act_bwd: channels must be 256");
+    if (!bn_shape_ok(rows, channels)) return set_error(HIVE_E_ARG, kBnShapeMsg);
     hipStream_t s = (hipStream_t)stream;
+    const int C = channels;
+    rows = rows * C / kBnC;
     const int grid = (int)((rows + 7) / 8 < kBnGrid ? (rows + 7) / 8 : kBnGrid);
+    const int fgrid = C >= 8 ? C / 8 : 1;
     float *partial = workspace, *coef = workspace + (long long)kBnGrid * 2 * kBnC;
     const __bf16 *DY = (const __bf16 *)dy, *X = (const __bf16 *)x, *Y = (const __bf16 *)y;
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(grid), dim3(kBnThreads), 0, s, DY, Y, X, save_mean, save_invstd, rows, relu,
-                       partial);
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(kFinishGrid), dim3(kBnThreads), 0, s, partial, grid, rows, gamma, save_invstd, dgamma,
-                       dbeta, coef);
+                       partial, C);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fgrid), dim3(kBnThreads), 0, s, partial, grid, rows, gamma, save_invstd, dgamma,
+                       dbeta, coef, C);
     if (dresidual)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), dim3(grid), dim3(kBnThreads), 0, s, DY, Y, X, save_mean, save_invstd,
-                           coef, rows, relu, (__bf16 *)dx, (__bf16 *)dresidual);
+                           coef, rows, relu, (__bf16 *)dx, (__bf16 *)dresidual, C - 1);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), dim3(grid), dim3(kBnThreads), 0, s, DY, Y, X, save_mean, save_invstd,
-                           coef, rows, relu, (__bf16 *)dx, (__bf16 *)dresidual);
+                           coef, rows, relu, (__bf16 *)dx, (__bf16 *)dresidual, C - 1);
     BN_TRY(hipGetLastError());
     return HIVE_OK;
 }

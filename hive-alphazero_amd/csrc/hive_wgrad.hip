@@ -242,7 +242,7 @@ conv3x3_wgrad_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ DY
 
 // dW[tap][k][c] = sum over the board ranges of the partial tiles; one thread per (slice, wave, tile, lane) float4
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float *__restrict__ WS, float *__restrict__ DW, int splits)
+wgrad_reduce_kernel(const float *__restrict__ WS, float *__restrict__ DW, int splits, int k_major)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;              // = ((slice * 8 + wave) * 36 + tile) * 64 + lane
     if (i >= 8 * 8 * 36 * 64) return;
@@ -256,6 +256,11 @@ wgrad_reduce_kernel(const float *__restrict__ WS, float *__restrict__ DW, int sp
     const int tap = tile >> 2, mt = (tile >> 1) & 1, nt = tile & 1;
     const int ks = slice >> 2, cs = slice & 3, wk = wave >> 1, wc = wave & 1, grp = lane >> 4, li = lane & 15;
     const int k0 = ks * kWgKS + 32 * wk + 16 * mt + 4 * grp, c = cs * kWgCS + 32 * wc + 16 * nt + li;
+    if (k_major) {                     // [k][tap][c]: the memory of a torch.channels_last nn.Conv2d weight
+        float *d = DW + ((long long)k0 * 9 + tap) * 256 + c;
+        d[0] = a.x; d[9 * 256] = a.y; d[18 * 256] = a.z; d[27 * 256] = a.w;
+        return;
+    }
     float *d = DW + ((long long)tap * 256 + k0) * 256 + c;
     d[0] = a.x; d[256] = a.y; d[512] = a.z; d[768] = a.w;
 }
@@ -273,7 +278,21 @@ static int g_wg_debug_order = -1;
 extern "C" void hive_nn_wgrad_debug_order(int v) { g_wg_debug_order = v; }
 #endif
 
+static int wgrad_launch(const void *x, const void *dy, float *dw, int batch, float *workspace, int k_major, void *stream);
+
 extern "C" int hive_nn_conv3x3_wgrad(const void *x, const void *dy, float *dw, int batch, float *workspace, void *stream)
+{
+    return wgrad_launch(x, dy, dw, batch, workspace, 0, stream);
+}
+
+extern "C" int hive_nn_conv3x3_wgrad_layout(const void *x, const void *dy, float *dw, int batch, float *workspace, int layout,
+                                            void *stream)
+{
+    if (layout != 0 && layout != 1) return set_error(HIVE_E_ARG, "hive_nn_conv3x3_wgrad_layout: layout must be 0 or 1");
+    return wgrad_launch(x, dy, dw, batch, workspace, layout, stream);
+}
+
+static int wgrad_launch(const void *x, const void *dy, float *dw, int batch, float *workspace, int k_major, void *stream)
 {
     if (!x || !dy || !dw || !workspace || batch <= 0) return set_error(HIVE_E_ARG, "hive_nn_conv3x3_wgrad: bad argument");
     hipStream_t s = (hipStream_t)stream;
@@ -286,7 +305,7 @@ extern "C" int hive_nn_conv3x3_wgrad(const void *x, const void *dy, float *dw, i
 #endif
     hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)(8 * splits)), dim3(kWgThreads), 0, s, (const __bf16 *)x,
                        (const __bf16 *)dy, workspace, batch, splits, xcd_order);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((kWgOut / 4 + 255) / 256)), dim3(256), 0, s, workspace, dw, splits);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((kWgOut / 4 + 255) / 256)), dim3(256), 0, s, workspace, dw, splits, k_major);
     e = hipGetLastError();
     if (e != hipSuccess) return set_error(HIVE_E_DEVICE, std::string("hive_nn_conv3x3_wgrad: ") + hipGetErrorString(e));
     return HIVE_OK;

@@ -98,6 +98,12 @@ long long hive_nn_tower72_plan_bytes(int batch);
  * with cin = 256 and no residual (two boards per workgroup; bit-identical to it).  What the training step's forward and
  * data-gradient convolutions run on (alpha_net.py:117-162 as executed by alpha_net.Trainer). */
 int hive_nn_conv72(const void *x, const void *w, const float *bias, void *y, int batch, int relu, int dtype, void *stream);
+/* ... with a residual: y = [relu](conv(x, w) + bias + residual), the sum taken in fp32 before the one rounding (the
+ * arithmetic of hive_nn_conv3x3_dt with a residual; bit-identical to it).  residual may be y itself (in place), not x.
+ * The training step's backward uses it for the gradient that reaches a residual block's input on two ways: dx =
+ * dgrad_conv1(dy) + dskip in one pass instead of a convolution and an elementwise add (alpha_net.py:36-54). */
+int hive_nn_conv72_add(const void *x, const void *w, const float *bias, const void *residual, void *y, int batch, int relu,
+                       int dtype, void *stream);
 
 /* need int8[batch] (1 = evaluate) -> rows int32[batch] (indices of the flagged boards, ascending), *nrows = their number. */
 int hive_nn_compact_rows(const int8_t *need, int batch, int32_t *rows, int32_t *nrows, void *stream);
@@ -127,7 +133,11 @@ int hive_nn_heads_splits(int batch);
  *             `momentum` and the unbiased variance like torch.nn.BatchNorm2d; save_mean / save_invstd f32[256] out.
  *   backward: dx (bf16), dgamma / dbeta (f32[256]) and, when dresidual != NULL, dresidual = dy * (y > 0) (bf16) --
  *             the gradient that flows into the skip input; y is only read when relu != 0.
- *   workspace: device f32[hive_nn_bn_workspace_floats()], contents undefined between calls; channels must be 256. */
+ *   workspace: device f32[hive_nn_bn_workspace_floats()], contents undefined between calls.
+ *   channels: 256 (the tower), or any smaller power of two whose [rows][channels] matrix is a whole number of 256-wide
+ *   rows (the heads' BatchNorm2d(128) and BatchNorm2d(1), alpha_net.py:56-80: the matrix is streamed as [rows *
+ *   channels / 256][256] and the columns of a channel are added up); the per-channel arrays then hold `channels`
+ *   entries. */
 int hive_nn_bn_workspace_floats(void);
 int hive_nn_bn_act_fwd(const void *x, const void *residual, const float *gamma, const float *beta, float *running_mean,
                        float *running_var, float momentum, float eps, void *y, float *save_mean, float *save_invstd,
@@ -141,6 +151,11 @@ int hive_nn_bn_act_bwd(const void *dy, const void *x, const void *y, const float
  * or 256; out = bf16[9 * cinp * 256], cinp = cin rounded up to 64).  transpose != 0 (cin = 256 only) packs the weights
  * of the data-gradient convolution: hive_nn_conv3x3(dy, 256, packed_T, ...) then returns dx of y = conv3x3(x, w). */
 int hive_nn_pack_conv3x3_weights(const float *w, int cin, int transpose, int channels_last, void *out, void *stream);
+/* The same for n 256 -> 256 convolutions in ONE launch, both forms: weights = DEVICE array of n device pointers (f32
+ * [256][256][3][3], all stored the same way), out_fwd / out_t = bf16[n][9 * 256 * 256] (forward form and data-gradient form of
+ * weight i at offset i * 589824).  A training step packs its 38 tower convolutions once, up front, instead of 77 times. */
+int hive_nn_pack_conv3x3_weights_multi(const float *const *weights, int n, int channels_last, void *out_fwd, void *out_t,
+                                       void *stream);
 
 /* Weight gradient of a 3x3 / stride 1 / zero-padded convolution with 256 input and 256 output channels (what autograd
  * computes for ResBlock.conv1/conv2.weight in the training step, alpha_net.py:36-54,117-162):
@@ -151,6 +166,11 @@ int hive_nn_pack_conv3x3_weights(const float *w, int cin, int transpose, int cha
  *   workspace: device f32[hive_nn_wgrad_workspace_floats()] (75 MB of partial sums), contents undefined between calls. */
 int hive_nn_wgrad_workspace_floats(void);
 int hive_nn_conv3x3_wgrad(const void *x, const void *dy, float *dw, int batch, float *workspace, void *stream);
+/* The same with the output order chosen: layout 0 = dw[ty][tx][k][c] (as above), 1 = dw[k][ty][tx][c], the memory of a
+ * torch.channels_last nn.Conv2d weight -- the gradient can then be handed to autograd with the parameter's own strides
+ * (no strided copy when it is accumulated). */
+int hive_nn_conv3x3_wgrad_layout(const void *x, const void *dy, float *dw, int batch, float *workspace, int layout,
+                                 void *stream);
 
 #ifdef __cplusplus
 }

@@ -328,22 +328,26 @@ def test_trainer_ddp_world_size_2_gloo(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (False, False)])
-def test_hip_bn_act_matches_torch(with_res, relu):
+@pytest.mark.parametrize("C", [256, 128, 1])
+def test_hip_bn_act_matches_torch(with_res, relu, C):
     """csrc/hive_train.hip against torch.nn.BatchNorm2d (training mode, fp32 math on the same bf16 inputs):
     output, input / skip / parameter gradients, running statistics.  Tolerances: one bf16 rounding of the output
     (2^-8 relative) on values of order 1; the gradient sums run over 144 * batch terms in fp32."""
     assert torch.cuda.is_available()
-    from hive_alphazero_amd.alpha_net import bn_act
+    from hive_alphazero_amd.alpha_net import bn_act, bn_act_ok
     torch.manual_seed(3)
-    B = 24
-    bn = torch.nn.BatchNorm2d(256).cuda()
-    ref = torch.nn.BatchNorm2d(256).cuda()
+    B = 24 if C == 256 else 32           # C = 128 / 1: the heads' BatchNorms (columns of a channel folded; 32 * 144 * 1 = 18 rows of 256)
+    bn = torch.nn.BatchNorm2d(C).cuda()
+    ref = torch.nn.BatchNorm2d(C).cuda()
     with torch.no_grad():
         bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
         ref.weight.copy_(bn.weight); ref.bias.copy_(bn.bias)
-    x = (torch.randn((B, 256, 12, 12), device="cuda") * 1.7 + 0.3).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    r = torch.randn((B, 256, 12, 12), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    dy = torch.randn((B, 256, 12, 12), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = (torch.randn((B, C, 12, 12), device="cuda") * 1.7 + 0.3).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    r = torch.randn((B, C, 12, 12), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn((B, C, 12, 12), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert bn_act_ok(x)
+    if C == 1:
+        assert not bn_act_ok(x[:3])      # 3 * 144 values are not a whole number of 256-wide rows: the caller keeps the library path
     x1, r1 = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
     y = bn_act(x1, bn, residual=r1 if with_res else None, relu=relu)
     y.backward(dy)
@@ -444,6 +448,99 @@ def test_hip_training_conv_matches_torch(cin, weights_cl):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("weights_cl", [False, True])
+def test_hip_weights_packed_in_one_launch_equal_the_single_packs(weights_cl):
+    """hive_nn_pack_conv3x3_weights_multi (all tower convolutions of a training step, forward and data-gradient form,
+    one launch) against hive_nn_pack_conv3x3_weights per weight: the same bytes; and a FusedTrainNet step with and
+    without it: the same loss and gradients, bit for bit."""
+    assert torch.cuda.is_available()
+    import ctypes
+    import hive_alphazero_amd as h
+    from hive_alphazero_amd import alpha_net as A
+    L = h.load()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ws = [torch.randn((256, 256, 3, 3), device="cuda", generator=g) for _ in range(5)]
+    if weights_cl:
+        ws = [w.contiguous(memory_format=torch.channels_last) for w in ws]
+    table = torch.tensor([w.data_ptr() for w in ws], dtype=torch.int64).cuda()
+    fwd = torch.zeros((5, 9 * 256 * 256), dtype=torch.bfloat16, device="cuda")
+    bwd = torch.zeros_like(fwd)
+    assert L.hive_nn_pack_conv3x3_weights_multi(P(table), 5, int(weights_cl), P(fwd), P(bwd), None) == 0, L.hive_last_error()
+    one = torch.zeros(9 * 256 * 256, dtype=torch.bfloat16, device="cuda")
+    for i, w in enumerate(ws):
+        for tr, got in ((0, fwd), (1, bwd)):
+            assert L.hive_nn_pack_conv3x3_weights(P(w), 256, tr, int(weights_cl), P(one), None) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(one.view(torch.int16), got[i].view(torch.int16)), (i, tr)
+    assert L.hive_nn_pack_conv3x3_weights_multi(None, 5, 0, P(fwd), P(bwd), None) == -1
+    assert L.hive_nn_pack_conv3x3_weights_multi(P(table), 0, 0, P(fwd), P(bwd), None) == -1
+    if not weights_cl:
+        return
+    # a whole forward + backward both ways: the tower's output bit for bit (this repo's kernels, deterministic); the heads
+    # and the loss run through the libraries, whose kernel choice depends on the allocator's state (measured: the policy
+    # differs by 6e-6 between two passes that differ only in when buffers were allocated), so loss and gradients are
+    # compared within a tolerance
+    res = {}
+    for once in (False, True):
+        torch.manual_seed(3)
+        net = A.ChessNet().cuda()
+        tr = A.Trainer(net)
+        assert isinstance(tr.model, A.FusedTrainNet)
+        tr.model.pack_once = once
+        acts = []
+        hook = net.outblock.conv.register_forward_pre_hook(lambda mod, inp: acts.append(inp[0].detach().clone()))   # the tower's output
+        gg = torch.Generator(device="cuda").manual_seed(9)
+        x = (torch.rand((16, 56, 12, 12), device="cuda", generator=gg) < 0.1).float()
+        pol = torch.softmax(torch.randn((16, 1584), device="cuda", generator=gg), dim=1)
+        val = torch.rand((16,), device="cuda", generator=gg) * 2 - 1
+        tr.model.train()
+        loss = tr.loss(x, pol, val)
+        loss.backward()
+        hook.remove()
+        res[once] = (loss.detach().clone(), {k: p_.grad.clone() for k, p_ in net.named_parameters()}, acts[0])
+    assert torch.equal(res[True][2], res[False][2])
+    assert abs(res[True][0].item() - res[False][0].item()) <= 1e-5
+    for k, a in res[True][1].items():
+        if k.endswith("weight") and a.dim() == 4:      # (biases in front of a BatchNorm have a zero gradient up to rounding)
+            b = res[False][1][k]
+            assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item() + 1e-7, k
+
+
+@pytest.mark.gpu
+def test_skip_gradient_summed_inside_the_data_gradient_convolution():
+    """A residual block's input reaches the output on two ways (conv1 and the skip connection).  Linked
+    (FusedTrainNet.fuse_skip_grad), bn2's backward hands the skip gradient to conv1's backward, whose data-gradient launch
+    adds it in fp32 before its one rounding (hive_nn_conv72_add) -- instead of autograd adding two bf16 tensors.  Against the
+    unlinked operators on the same block: parameter gradients bit for bit (they do not depend on the sum), the input
+    gradient within one bf16 rounding of the sum."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.alpha_net import ResBlock, bn_act, conv3x3
+    torch.manual_seed(21)
+    B = 10
+    blk = ResBlock().cuda().to(memory_format=torch.channels_last)
+    x = torch.randn((B, 256, 12, 12), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn((B, 256, 12, 12), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for linked in (False, True):
+        blk.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        s = xi * 1                                    # (a non-leaf input, as inside the tower)
+        link = {} if linked else None
+        out = bn_act(conv3x3(s, blk.conv1, link=link), blk.bn1)
+        y = bn_act(conv3x3(out, blk.conv2), blk.bn2, residual=s, link=link)
+        y.backward(dy)
+        assert not link                               # the handed-over gradient was consumed
+        res[linked] = (y.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in blk.parameters()])
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b)
+    gx_l, gx_u = res[True][1].float(), res[False][1].float()
+    assert (gx_l - gx_u).abs().max().item() <= 2 ** -7 * gx_u.abs().max().item()
+    assert not torch.equal(gx_l, gx_u)               # (one rounding instead of two: not the same bits)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("batch", [1, 8, 37, 512])
 def test_hip_weight_gradient_matches_fp32_convolution_backward(batch):
     """hive_nn_conv3x3_wgrad (pixels as the MFMA contraction, both operands through transposing LDS reads, split over
@@ -475,6 +572,12 @@ def test_hip_weight_gradient_matches_fp32_convolution_backward(batch):
     L.hive_nn_conv3x3_wgrad(p(x), p(dy), p(taps), batch, p(ws), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert torch.equal(taps, first)
+    # the same sums in a torch.channels_last weight's memory order ([k][ty][tx][c], hive_nn_conv3x3_wgrad_layout 1)
+    cl = torch.full((256, 3, 3, 256), float("nan"), dtype=torch.float32, device="cuda")
+    assert L.hive_nn_conv3x3_wgrad_layout(p(x), p(dy), p(cl), batch, p(ws), 1, None) == 0, L.hive_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(cl.permute(1, 2, 0, 3), first)
+    assert L.hive_nn_conv3x3_wgrad_layout(p(x), p(dy), p(cl), batch, p(ws), 2, None) == -1
 
 
 @pytest.mark.gpu
@@ -826,6 +929,19 @@ def test_hip_tower72_matches_resblock_chain(dtype):
             torch.cuda.synchronize()
             assert torch.equal(got, want), (B, relu, int((got != want).sum()))
             assert relu or bool((got.float() < 0).any())
+            # ... + residual (hive_nn_conv72_add), into a third buffer and in place over the residual
+            r = torch.randn((B, 144, 256), device="cuda", generator=gen).to(dtype)
+            want = torch.full_like(x, 7.0)
+            _lib.check(L.hive_nn_conv3x3_dt(P(x), 256, P(w1), P(b1), P(r), P(want), B, relu, DT, st()))
+            got = torch.full_like(x, 7.0)
+            _lib.check(L.hive_nn_conv72_add(P(x), P(w1), P(b1), P(r), P(got), B, relu, DT, st()))
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), ("add", B, relu, int((got != want).sum()))
+            inplace = r.clone()
+            _lib.check(L.hive_nn_conv72_add(P(x), P(w1), P(b1), P(inplace), P(inplace), B, relu, DT, st()))
+            torch.cuda.synchronize()
+            assert torch.equal(inplace, want), ("add in place", B, relu, int((inplace != want).sum()))
+    assert L.hive_nn_conv72_add(P(x), P(w1), P(b1), None, P(got), B, 0, DT, st()) != 0
     # arguments: rows without a count, aliased output
     assert L.hive_nn_tower72(P(x), P(w), P(bias), P(y), B, nblk, DT, P(y), None, st()) != 0
     assert L.hive_nn_tower72(P(x), P(w), P(bias), P(x), B, nblk, DT, None, None, st()) != 0

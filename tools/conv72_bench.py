@@ -12,8 +12,12 @@ for B in [int(a) for a in sys.argv[1:]] or [256, 512, 1024]:
     w = (torch.randn((9 * 8 * 16 * 64 * 8,), device="cuda") * 0.015).to(torch.bfloat16)
     b = torch.zeros((256,), device="cuda")
     y = torch.empty_like(x)
+    r = torch.randn((B, 144, 256), device="cuda").to(torch.bfloat16) * 0.01
     forms = {"conv3x3_kernel": lambda: L.hive_nn_conv3x3_dt(P(x), 256, P(w), P(b), None, P(y), B, 0, _lib.BF16, None),
-             "conv72 (asm)": lambda: L.hive_nn_conv72(P(x), P(w), P(b), P(y), B, 0, _lib.BF16, None)}
+             "conv72 (asm)": lambda: L.hive_nn_conv72(P(x), P(w), P(b), P(y), B, 0, _lib.BF16, None),
+             "conv72 + residual": lambda: L.hive_nn_conv72_add(P(x), P(w), P(b), P(r), P(y), B, 0, _lib.BF16, None),
+             "conv72 + residual in place": lambda: L.hive_nn_conv72_add(P(x), P(w), P(b), P(r), P(r), B, 0, _lib.BF16, None),
+             "conv72, then torch add": lambda: (L.hive_nn_conv72(P(x), P(w), P(b), P(y), B, 0, _lib.BF16, None), r.add_(y))}
     res = {k: [] for k in forms}
     for k, f in forms.items():
         f()
