@@ -42,9 +42,9 @@ ABI_SYMBOLS = [
     "hive_search_leaf_need",
     # include/hive_nn.h
     "hive_nn_conv3x3", "hive_nn_resblock", "hive_nn_conv3x3_dt", "hive_nn_resblock_dt", "hive_nn_tower",
-    "hive_nn_conv3x3_sel", "hive_nn_resblock_sel", "hive_nn_copy_rows", "hive_nn_tower72", "hive_nn_compact_rows", "hive_nn_tower72_balanced", "hive_nn_tower72_plan_bytes", "hive_nn_conv72", "hive_nn_conv72_add",
+    "hive_nn_conv3x3_sel", "hive_nn_resblock_sel", "hive_nn_copy_rows", "hive_nn_tower72", "hive_nn_compact_rows", "hive_nn_tower72_balanced", "hive_nn_tower72_plan_bytes", "hive_nn_conv72", "hive_nn_conv72_add", "hive_nn_conv72_stats",
     "hive_nn_heads", "hive_nn_heads_workspace_bytes", "hive_nn_heads_splits",
-    "hive_nn_bn_workspace_floats", "hive_nn_bn_act_fwd", "hive_nn_bn_act_bwd",
+    "hive_nn_bn_workspace_floats", "hive_nn_bn_act_fwd", "hive_nn_bn_act_fwd_partial", "hive_nn_bn_act_bwd",
     "hive_nn_pack_conv3x3_weights", "hive_nn_pack_conv3x3_weights_multi", "hive_nn_conv3x3_wgrad", "hive_nn_conv3x3_wgrad_layout", "hive_nn_wgrad_workspace_floats",
 ]
 
@@ -136,6 +136,7 @@ def load():
     L.hive_nn_tower72_balanced.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.hive_nn_conv72.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.hive_nn_conv72_add.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.hive_nn_conv72_stats.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
     L.hive_nn_tower72_plan_bytes.argtypes = [i32]
     L.hive_nn_tower72_plan_bytes.restype = ctypes.c_longlong
     L.hive_nn_heads.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -152,6 +153,7 @@ def load():
     f32, i64 = ctypes.c_float, ctypes.c_longlong
     L.hive_nn_bn_workspace_floats.restype = i32
     L.hive_nn_bn_act_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i64, i32, i32, vp]
+    L.hive_nn_bn_act_fwd_partial.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, i32, i64, i32, vp]
     L.hive_nn_bn_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
     L.hive_nn_pack_conv3x3_weights.argtypes = [vp, i32, i32, i32, vp, vp]
     L.hive_nn_pack_conv3x3_weights_multi.argtypes = [vp, i32, i32, vp, vp, vp]

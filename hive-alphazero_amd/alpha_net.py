@@ -150,7 +150,7 @@ class _BNAct(torch.autograd.Function):
     smaller power of two (the heads' 128 and 1; bn_act_ok tells whether a shape qualifies)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, bn, relu, track=True, link=None):
+    def forward(ctx, x, gamma, beta, residual, bn, relu, track=True, link=None, stats=None):
         """link: a dict shared with the _Conv3x3 that consumes the same `residual` tensor (a residual block's first
         convolution): the backward then leaves the skip gradient there instead of returning it, and that convolution's
         data gradient adds it in its epilogue (one pass instead of a convolution and autograd's elementwise add)."""
@@ -167,9 +167,16 @@ class _BNAct(torch.autograd.Function):
         invstd = torch.empty(C, dtype=torch.float32, device=dev)
         ws = torch.empty(L.hive_nn_bn_workspace_floats(), dtype=torch.float32, device=dev)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-        _lib.check(L.hive_nn_bn_act_fwd(p(x), p(res), p(gamma), p(beta), p(bn.running_mean), p(bn.running_var),
-                                        float(bn.momentum), float(bn.eps), p(y), p(mean), p(invstd), p(ws), rows, C,
-                                        int(relu), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        part = stats.pop("partial", None) if stats is not None else None
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if part is not None and C == 256:      # the convolution in front has added up its output already (hive_nn_conv72_stats)
+            _lib.check(L.hive_nn_bn_act_fwd_partial(p(x), p(res), p(gamma), p(beta), p(bn.running_mean), p(bn.running_var),
+                                                    float(bn.momentum), float(bn.eps), p(y), p(mean), p(invstd), p(ws), p(part),
+                                                    part.shape[0], rows, int(relu), st))
+        else:
+            _lib.check(L.hive_nn_bn_act_fwd(p(x), p(res), p(gamma), p(beta), p(bn.running_mean), p(bn.running_var),
+                                            float(bn.momentum), float(bn.eps), p(y), p(mean), p(invstd), p(ws), rows, C,
+                                            int(relu), st))
         if track:
             bn.num_batches_tracked += 1
         ctx.save_for_backward(x, y, gamma, mean, invstd)
@@ -197,7 +204,7 @@ class _BNAct(torch.autograd.Function):
         if ctx.link is not None:
             ctx.link["dres"] = dres                 # picked up (and added to its own dx) by the linked convolution's backward
             dres = None
-        return dx, dgamma, dbeta, dres, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None
 
 
 _CONST_CACHE = {}
@@ -225,7 +232,7 @@ class _Conv3x3(torch.autograd.Function):
     asm_conv = True          # forward / data gradient of the 256 -> 256 convolutions on hive_nn_conv72
 
     @staticmethod
-    def forward(ctx, x, weight, bias, packed=None, packed_t=None, link=None):
+    def forward(ctx, x, weight, bias, packed=None, packed_t=None, link=None, stats=None):
         """packed / packed_t: this weight already in the kernels' layout (forward / data-gradient form), as
         FusedTrainNet packs all tower convolutions of a step in one launch; None: packed here.  link: see _BNAct."""
         from . import _lib
@@ -247,7 +254,12 @@ class _Conv3x3(torch.autograd.Function):
         ctx.link = link
         b = bias if bias is not None else _const("zero_bias", 0, dev)
         y = torch.empty((B, 256, 12, 12), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
-        if cin == 256 and _Conv3x3.asm_conv:         # the 72-tile assembly kernel (two boards per workgroup): same bits
+        if cin == 256 and _Conv3x3.asm_conv and stats is not None and B % 2 == 0:
+            # ... and the BatchNorm behind it gets its per-channel sums from this launch (stats: a dict shared with that bn_act)
+            part = torch.empty((B // 2, 2, 256), dtype=torch.float32, device=dev)
+            _lib.check(L.hive_nn_conv72_stats(p(x), p(wp), p(b), p(y), B, 0, _lib.BF16, p(part), st))
+            stats["partial"] = part
+        elif cin == 256 and _Conv3x3.asm_conv:       # the 72-tile assembly kernel (two boards per workgroup): same bits
             _lib.check(L.hive_nn_conv72(p(x), p(wp), p(b), p(y), B, 0, _lib.BF16, st))
         else:
             _lib.check(L.hive_nn_conv3x3(p(x), cin, p(wp), p(b), None, p(y), B, 0, st))
@@ -300,7 +312,7 @@ class _Conv3x3(torch.autograd.Function):
             dw = torch.ops.aten.convolution_backward(dy, x, _const("weight_like", cin, dev), None, (1, 1), (1, 1), (1, 1), False,
                                                      (0, 0), 1, (False, True, False))[1].float()
         db = dy.float().sum(dim=(0, 2, 3)) if ctx.has_bias else None
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 def _wgrad_workspace(L, dev):
@@ -320,9 +332,10 @@ def _weight_layout(w):
     return w.contiguous(), 0
 
 
-def conv3x3(x, conv, packed=None, packed_t=None, link=None):
-    """conv(x) for a 3x3 / stride 1 / padding 1 nn.Conv2d with 256 output channels, through the HIP kernel."""
-    return _Conv3x3.apply(x, conv.weight, conv.bias, packed, packed_t, link)
+def conv3x3(x, conv, packed=None, packed_t=None, link=None, stats=None):
+    """conv(x) for a 3x3 / stride 1 / padding 1 nn.Conv2d with 256 output channels, through the HIP kernel.  stats: a dict
+    shared with the bn_act that normalises the result (the convolution launch then adds up the BatchNorm statistics)."""
+    return _Conv3x3.apply(x, conv.weight, conv.bias, packed, packed_t, link, stats)
 
 
 def bn_act_ok(x):
@@ -332,10 +345,10 @@ def bn_act_ok(x):
     return x.is_cuda and 1 <= C <= 256 and (C & (C - 1)) == 0 and (x.shape[0] * x.shape[2] * x.shape[3] * C) % 256 == 0
 
 
-def bn_act(x, bn, residual=None, relu=True, track=True, link=None):
+def bn_act(x, bn, residual=None, relu=True, track=True, link=None, stats=None):
     """relu(bn(x) + residual) in training mode through the HIP kernels (updates bn's running statistics; track=False
     leaves num_batches_tracked to the caller, who can bump all layers' counters in one launch; link: see _BNAct)."""
-    return _BNAct.apply(x, bn.weight, bn.bias, residual, bn, relu, track, link)
+    return _BNAct.apply(x, bn.weight, bn.bias, residual, bn, relu, track, link, stats)
 
 
 class FusedTrainNet(nn.Module):
@@ -346,6 +359,7 @@ class FusedTrainNet(nn.Module):
     pack_once = True         # the 38 tower convolutions' weights packed by ONE launch per step (both forms)
     hip_head_bn = True       # the heads' BatchNorm2d(1) / BatchNorm2d(128) + ReLU on the HIP kernels too
     fuse_skip_grad = True    # a block input's two gradients (conv1's data gradient + the skip's) summed in the convolution launch
+    fuse_bn_stats = True     # a tower convolution adds up the statistics of the BatchNorm behind it (no separate pass over its output)
 
     def __init__(self, net, hip_conv=True):
         super().__init__()
@@ -390,13 +404,16 @@ class FusedTrainNet(nn.Module):
         pk = (lambda j: (packed[0][j], packed[1][j])) if packed is not None else (lambda j: (None, None))
         s = bn_act(conv(s, net.conv.conv1), net.conv.bn1, track=False)
         counters = [net.conv.bn1.num_batches_tracked]
+        fs = self.fuse_bn_stats and self.hip_conv
         for i in range(19):
             blk = getattr(net, "res_%i" % i)
             # the block's input feeds conv1 and the skip connection: its two gradients are summed inside conv1's data-gradient
             # launch (hive_nn_conv72_add) when the two operators are linked
             link = {} if (self.fuse_skip_grad and self.hip_conv and s.requires_grad) else None
-            out = bn_act(conv(s, blk.conv1, *pk(2 * i), link=link), blk.bn1, track=False)
-            s = bn_act(conv(out, blk.conv2, *pk(2 * i + 1)), blk.bn2, residual=s, track=False, link=link)
+            st1 = {} if fs else None
+            st2 = {} if fs else None
+            out = bn_act(conv(s, blk.conv1, *pk(2 * i), link=link, stats=st1), blk.bn1, track=False, stats=st1)
+            s = bn_act(conv(out, blk.conv2, *pk(2 * i + 1), stats=st2), blk.bn2, residual=s, track=False, link=link, stats=st2)
             counters += [blk.bn1.num_batches_tracked, blk.bn2.num_batches_tracked]
         out, hb = net.outblock, self.hip_head_bn
         v = out.conv(s)                            # OutBlock.forward (alpha_net.py:67-80) with the two BatchNorms on the HIP kernels

@@ -85,7 +85,10 @@ S_FLAG = 70                   # pair: address of the current pair's hand-over fl
 S_FLAGS = 76                  # kernarg flags: bit 0 = ONE convolution per block (conv + bias [+ ReLU] -> y), bit 1 = no ReLU,
                               # bit 2 (with bit 0) = ... + residual: the convolution runs as a block's SECOND one, whose epilogue adds a
                               # skip operand -- here the rows of the kernarg `residual` instead of the block's input
-S_RES = 78                    # pair: kernarg residual (flags bit 2)
+                              # bit 3 (with bit 0, without bit 2) = ... and the per-channel sum / sum of squares of the workgroup's
+                              # output (as stored: after the rounding) -> aux[workgroup][2][256] floats: the statistics pass of a
+                              # training-mode BatchNorm behind the convolution
+S_RES = 78                    # pair: kernarg aux: the residual (flags bit 2) or the statistics rows (bit 3)
 S_STG0, S_STG1 = 72, 74       # pairs: where the current segment's boards are staged from (X rows, or Y rows for a tail)
 PLAN_STRIDE = 32              # bytes per workgroup in the plan
 MAX_WG = 256                  # workgroups a plan covers; the flags start at plan + MAX_WG * PLAN_STRIDE
@@ -681,23 +684,74 @@ def gen_kernel(name, dt, debug=0):
         A.drain()
         stamp(2)
     A.wait(vm_tag=("bias", MT - 1))
-    k = 0
-    for nt in range(NT):
-        for mt in range(MT):
-            t = nt * MT + mt
-            tmp = V_T + 10 * (k % 3)
-            k += 1
-            src = tile_src(t, tmp)
-            e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 4, 2), vr(src, 2), vr(V_BIAS + 4 * mt, 2)))
-            e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 6, 2), vr(src + 2, 2), vr(V_BIAS + 4 * mt + 2, 2)))
-            for i in range(4):
-                e("v_max_f32_e32 %s, %s, %s" % (vr(tmp + 4 + i), vr(V_FLOOR), vr(tmp + 4 + i)))
-            e("%s %s, %s, %s" % (cvt, vr(tmp + 8), vr(tmp + 4), vr(tmp + 5)))
-            e("%s %s, %s, %s" % (cvt, vr(tmp + 9), vr(tmp + 6), vr(tmp + 7)))
-            if len(A.lg_q) >= 3:
-                A.wait(lg_tag=A.lg_q[-3])            # (the temporaries of three tiles ago are free again)
-            A.lg("ds_write_b64 %s, %s offset:%d" % (vr(V_LDSW + nt // 7), vr(tmp + 8, 2), (nt % 7) * 16 * PS + mt * 32), ("w1", t))
+
+    def epilogue1_tiles(stats):
+        """stats: also add every stored value (the 16-bit result, widened again) and its square into this lane's 2 x 16 sums
+        V_SK[0:15] (sum) / V_SK[16:31] (squares), indexed [channel tile][row of the lane]; V_SK is idle in this epilogue."""
+        k = 0
+        for nt in range(NT):
+            for mt in range(MT):
+                t = nt * MT + mt
+                tmp = V_T + 10 * (k % 3)
+                k += 1
+                src = tile_src(t, tmp)
+                e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 4, 2), vr(src, 2), vr(V_BIAS + 4 * mt, 2)))
+                e("v_pk_add_f32 %s, %s, %s" % (vr(tmp + 6, 2), vr(src + 2, 2), vr(V_BIAS + 4 * mt + 2, 2)))
+                for i in range(4):
+                    e("v_max_f32_e32 %s, %s, %s" % (vr(tmp + 4 + i), vr(V_FLOOR), vr(tmp + 4 + i)))
+                e("%s %s, %s, %s" % (cvt, vr(tmp + 8), vr(tmp + 4), vr(tmp + 5)))
+                e("%s %s, %s, %s" % (cvt, vr(tmp + 9), vr(tmp + 6), vr(tmp + 7)))
+                if len(A.lg_q) >= 3:
+                    A.wait(lg_tag=A.lg_q[-3])            # (the temporaries of three tiles ago are free again)
+                A.lg("ds_write_b64 %s, %s offset:%d" % (vr(V_LDSW + nt // 7), vr(tmp + 8, 2), (nt % 7) * 16 * PS + mt * 32), ("w1", t))
+                if not stats:
+                    continue
+                if dt == "bf16":
+                    e("v_lshlrev_b32_e32 %s, 16, %s" % (vr(tmp + 0), vr(tmp + 8)))
+                    e("v_and_b32_e32 %s, 0xffff0000, %s" % (vr(tmp + 1), vr(tmp + 8)))
+                    e("v_lshlrev_b32_e32 %s, 16, %s" % (vr(tmp + 2), vr(tmp + 9)))
+                    e("v_and_b32_e32 %s, 0xffff0000, %s" % (vr(tmp + 3), vr(tmp + 9)))
+                else:
+                    e("v_cvt_f32_f16_e32 %s, %s" % (vr(tmp + 0), vr(tmp + 8)))
+                    e("v_cvt_f32_f16_sdwa %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" % (vr(tmp + 1), vr(tmp + 8)))
+                    e("v_cvt_f32_f16_e32 %s, %s" % (vr(tmp + 2), vr(tmp + 9)))
+                    e("v_cvt_f32_f16_sdwa %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" % (vr(tmp + 3), vr(tmp + 9)))
+                sm, sq = V_SK + 4 * mt, V_SK + 16 + 4 * mt
+                for h in (0, 2):
+                    if nt == 0:                          # (the first pixel tile starts the sums: no zeroing pass)
+                        e("v_pk_mul_f32 %s, %s, %s" % (vr(sq + h, 2), vr(tmp + h, 2), vr(tmp + h, 2)))
+                        e("v_mov_b32_e32 %s, %s" % (vr(sm + h), vr(tmp + h)))
+                        e("v_mov_b32_e32 %s, %s" % (vr(sm + h + 1), vr(tmp + h + 1)))
+                    else:
+                        e("v_pk_fma_f32 %s, %s, %s, %s" % (vr(sq + h, 2), vr(tmp + h, 2), vr(tmp + h, 2), vr(sq + h, 2)))
+                        e("v_pk_add_f32 %s, %s, %s" % (vr(sm + h, 2), vr(sm + h, 2), vr(tmp + h, 2)))
+
+    c("flags bit 3: the statistics variant of this epilogue")
+    e("s_bitcmp1_b32 %s, 3" % sr(S_FLAGS))
+    e("s_cbranch_scc1 .L%s_epi1stats" % name)
+    epilogue1_tiles(False)
     A.drain()
+    e("s_branch .L%s_epi1done" % name)
+    A.label(".L%s_epi1stats" % name)
+    epilogue1_tiles(True)
+    A.drain()
+    c("sums over the 16 lanes of a row (= the 16 pixels of a tile row): inclusive prefix sums, lane 15 of every row holds the total")
+    for shift in (1, 2, 4, 8):
+        for r in range(32):
+            e("v_add_f32_dpp %s, %s, %s row_shr:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (vr(V_SK + r), vr(V_SK + r), vr(V_SK + r), shift))
+    c("lanes 15 / 31 / 47 / 63 store: aux[workgroup][0][channel] = sum, [1][channel] = squares; channel = wave * 64 + tile * 16 + 4 * row group + i")
+    e("s_lshl_b32 %s, %s, 11" % (sr(S_T1), sr(S_PAIR)))
+    e("s_add_u32 %s, %s, %s" % (sr(S_SRC), sr(S_RES), sr(S_T1)))
+    e("s_addc_u32 %s, %s, 0" % (sr(S_SRC + 1), sr(S_RES + 1)))
+    e("s_mov_b32 exec_lo, 0x80008000")
+    e("s_mov_b32 exec_hi, 0x80008000")
+    for mt in range(MT):
+        A.vm("global_store_dwordx4 %s, %s, %s offset:%d" % (vr(V_BIASOFF), vr(V_SK + 4 * mt, 4), sr(S_SRC, 2), mt * 64), ("stat", mt))
+        A.vm("global_store_dwordx4 %s, %s, %s offset:%d" % (vr(V_BIASOFF), vr(V_SK + 16 + 4 * mt, 4), sr(S_SRC, 2), 1024 + mt * 64),
+             ("stat", 4 + mt))
+    e("s_mov_b64 exec, -1")
+    A.drain()
+    A.label(".L%s_epi1done" % name)
     stamp(3)
     e("s_barrier")                                   # the intermediate boards are complete
     stamp(4)

@@ -779,6 +779,15 @@ extern "C" int hive_nn_conv72_add(const void *x, const void *w, const float *bia
     return tower72_launch(x, w, bias, y, batch, 1, dtype, nullptr, nullptr, nullptr, stream, 1 | (relu ? 0 : 2) | 4, residual);
 }
 
+extern "C" int hive_nn_conv72_stats(const void *x, const void *w, const float *bias, void *y, int batch, int relu, int dtype,
+                                    float *partial, void *stream)
+{
+    // ... and (flags bit 3) every workgroup's per-channel sum / sum of squares of what it stored: partial[batch / 2][2][256]
+    if (!partial || batch % 2 != 0)
+        return set_error(HIVE_E_ARG, "hive_nn_conv72_stats: partial == NULL or an odd batch (a repeated tail board would be counted twice)");
+    return tower72_launch(x, w, bias, y, batch, 1, dtype, nullptr, nullptr, nullptr, stream, 1 | (relu ? 0 : 2) | 8, partial);
+}
+
 static int tower72_launch(const void *x, const void *w, const float *bias, void *y, int batch, int nblocks, int dtype,
                           const int32_t *rows, const int32_t *nrows, int32_t *plan, void *stream, int flags, const void *residual)
 {

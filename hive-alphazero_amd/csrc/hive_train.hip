@@ -415,6 +415,29 @@ extern "C" int hive_nn_bn_act_fwd(const void *x, const void *residual, const flo
     return HIVE_OK;
 }
 
+extern "C" int hive_nn_bn_act_fwd_partial(const void *x, const void *residual, const float *gamma, const float *beta,
+                                          float *running_mean, float *running_var, float momentum, float eps, void *y,
+                                          float *save_mean, float *save_invstd, float *workspace, const float *partial,
+                                          int parts, long long rows, int relu, void *stream)
+{
+    // hive_nn_bn_act_fwd for 256 channels without its statistics pass: `partial` = parts x [2][256] per-channel sums / sums of
+    // squares that together cover all `rows` positions (written by hive_nn_conv72_stats, the convolution in front)
+    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !workspace || !partial || parts <= 0 || rows <= 0)
+        return set_error(HIVE_E_ARG, "hive_nn_bn_act_fwd_partial: bad argument");
+    if ((running_mean == nullptr) != (running_var == nullptr))
+        return set_error(HIVE_E_ARG, "hive_nn_bn_act_fwd_partial: running_mean and running_var go together");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (int)((rows + 7) / 8 < kBnGrid ? (rows + 7) / 8 : kBnGrid);
+    float *coef = workspace + (long long)kBnGrid * 2 * kBnC;
+    const __bf16 *X = (const __bf16 *)x, *R = (const __bf16 *)residual;
+    hipLaunchKernelGGL(bn_fwd_finish_kernel, dim3(kBnC / 8), dim3(kBnThreads), 0, s, partial, parts, rows, gamma, beta, running_mean,
+                       running_var, momentum, eps, save_mean, save_invstd, coef, kBnC);
+    if (R) hipLaunchKernelGGL((bn_fwd_apply_kernel<true>), dim3(grid), dim3(kBnThreads), 0, s, X, R, coef, rows, relu, (__bf16 *)y, kBnC - 1);
+    else hipLaunchKernelGGL((bn_fwd_apply_kernel<false>), dim3(grid), dim3(kBnThreads), 0, s, X, R, coef, rows, relu, (__bf16 *)y, kBnC - 1);
+    BN_TRY(hipGetLastError());
+    return HIVE_OK;
+}
+
 extern "C" int hive_nn_bn_act_bwd(const void *dy, const void *x, const void *y, const float *gamma, const float *save_mean,
                                   const float *save_invstd, void *dx, void *dresidual, float *dgamma, float *dbeta,
                                   float *workspace, long long rows, int channels, int relu, void *stream)

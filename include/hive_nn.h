@@ -102,6 +102,11 @@ int hive_nn_conv72(const void *x, const void *w, const float *bias, void *y, int
  * arithmetic of hive_nn_conv3x3_dt with a residual; bit-identical to it).  residual may be y itself (in place), not x.
  * The training step's backward uses it for the gradient that reaches a residual block's input on two ways: dx =
  * dgrad_conv1(dy) + dskip in one pass instead of a convolution and an elementwise add (alpha_net.py:36-54). */
+/* ... with the statistics pass of a training-mode BatchNorm behind it: partial[batch / 2][2][256] floats = every
+ * workgroup's per-channel sum and sum of squares of the values it stored (the 16-bit results, widened again: exactly what
+ * a pass over y would add up).  batch must be even.  hive_nn_bn_act_fwd_partial consumes it. */
+int hive_nn_conv72_stats(const void *x, const void *w, const float *bias, void *y, int batch, int relu, int dtype,
+                         float *partial, void *stream);
 int hive_nn_conv72_add(const void *x, const void *w, const float *bias, const void *residual, void *y, int batch, int relu,
                        int dtype, void *stream);
 
@@ -142,6 +147,11 @@ int hive_nn_bn_workspace_floats(void);
 int hive_nn_bn_act_fwd(const void *x, const void *residual, const float *gamma, const float *beta, float *running_mean,
                        float *running_var, float momentum, float eps, void *y, float *save_mean, float *save_invstd,
                        float *workspace, long long rows, int channels, int relu, void *stream);
+/* hive_nn_bn_act_fwd (256 channels) without its statistics pass: partial = parts x [2][256] per-channel sums / sums of
+ * squares covering all `rows` positions (hive_nn_conv72_stats: parts = batch / 2). */
+int hive_nn_bn_act_fwd_partial(const void *x, const void *residual, const float *gamma, const float *beta, float *running_mean,
+                               float *running_var, float momentum, float eps, void *y, float *save_mean, float *save_invstd,
+                               float *workspace, const float *partial, int parts, long long rows, int relu, void *stream);
 int hive_nn_bn_act_bwd(const void *dy, const void *x, const void *y, const float *gamma, const float *save_mean,
                        const float *save_invstd, void *dx, void *dresidual, float *dgamma, float *dbeta,
                        float *workspace, long long rows, int channels, int relu, void *stream);

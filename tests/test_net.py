@@ -508,6 +508,40 @@ def test_hip_weights_packed_in_one_launch_equal_the_single_packs(weights_cl):
 
 
 @pytest.mark.gpu
+def test_batchnorm_statistics_added_up_by_the_convolution_launch():
+    """conv3x3(..., stats=d) + bn_act(..., stats=d): the convolution's epilogue adds up the BatchNorm's per-channel sums
+    (hive_nn_conv72_stats), the BatchNorm skips its own pass over the tensor (hive_nn_bn_act_fwd_partial).  Against the
+    unfused pair on the same operands: the same convolution output, statistics equal to fp32 summation order (1e-5), the
+    normalised output within one bf16 rounding, gradients likewise."""
+    assert torch.cuda.is_available()
+    from hive_alphazero_amd.alpha_net import ResBlock, bn_act, conv3x3
+    torch.manual_seed(22)
+    B = 12
+    blk = ResBlock().cuda().to(memory_format=torch.channels_last)
+    x = torch.randn((B, 256, 12, 12), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn((B, 256, 12, 12), device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for fused in (False, True):
+        blk.zero_grad(set_to_none=True)
+        blk.bn1.reset_running_stats()
+        xi = x.clone().requires_grad_(True)
+        d = {} if fused else None
+        y = bn_act(conv3x3(xi, blk.conv1, stats=d), blk.bn1, stats=d)
+        assert not d                                  # the partial sums were consumed
+        y.backward(dy)
+        res[fused] = (y.detach().float(), xi.grad.float(), blk.conv1.weight.grad.clone(), blk.bn1.weight.grad.clone(),
+                      blk.bn1.running_mean.clone(), blk.bn1.running_var.clone())
+    a, b = res[True], res[False]
+    assert (a[4] - b[4]).abs().max().item() <= 1e-5 * b[4].abs().max().item() + 1e-7
+    assert (a[5] - b[5]).abs().max().item() <= 1e-5 * b[5].abs().max().item()
+    assert (a[0] - b[0]).abs().max().item() <= 2 ** -7 * b[0].abs().max().item()
+    assert (a[0] != b[0]).float().mean().item() < 0.01          # (only values that sit on a rounding boundary move)
+    assert (a[1] - b[1]).abs().max().item() <= 2 ** -6 * b[1].abs().max().item()
+    assert (a[2] - b[2]).abs().max().item() <= 2 ** -6 * b[2].abs().max().item()
+    assert (a[3] - b[3]).abs().max().item() <= 1e-2 * b[3].abs().max().item()
+
+
+@pytest.mark.gpu
 def test_skip_gradient_summed_inside_the_data_gradient_convolution():
     """A residual block's input reaches the output on two ways (conv1 and the skip connection).  Linked
     (FusedTrainNet.fuse_skip_grad), bn2's backward hands the skip gradient to conv1's backward, whose data-gradient launch
@@ -942,6 +976,25 @@ def test_hip_tower72_matches_resblock_chain(dtype):
             torch.cuda.synchronize()
             assert torch.equal(inplace, want), ("add in place", B, relu, int((inplace != want).sum()))
     assert L.hive_nn_conv72_add(P(x), P(w1), P(b1), None, P(got), B, 0, DT, st()) != 0
+    # ... with the BatchNorm statistics of the output added up by the launch (hive_nn_conv72_stats): same output bits; the
+    # partial sums of all workgroups together = the per-channel sum / sum of squares of the STORED values (fp32 sums of up
+    # to 144 * B terms in another order: 1e-5 relative to the sum of magnitudes)
+    for B in (2, 6, 512):
+        x = torch.randn((B, 144, 256), device="cuda", generator=gen).to(dtype)
+        want, got = torch.full_like(x, 7.0), torch.full_like(x, 7.0)
+        part = torch.full((B // 2, 2, 256), float("nan"), dtype=torch.float32, device="cuda")
+        _lib.check(L.hive_nn_conv72(P(x), P(w1), P(b1), P(want), B, 0, DT, st()))
+        _lib.check(L.hive_nn_conv72_stats(P(x), P(w1), P(b1), P(got), B, 0, DT, P(part), st()))
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        yf = want.double().reshape(-1, 256)
+        s1, s2 = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+        assert torch.isfinite(part).all()
+        assert (s1 - yf.sum(0)).abs().max().item() <= 1e-5 * yf.abs().sum(0).max().item()
+        assert (s2 - (yf * yf).sum(0)).abs().max().item() <= 1e-5 * (yf * yf).sum(0).max().item()
+        # every workgroup's row = its own two boards
+        assert (part[0, 0].double() - want[:2].double().reshape(-1, 256).sum(0)).abs().max().item() <= 1e-4 * want[:2].double().abs().reshape(-1, 256).sum(0).max().item()
+    assert L.hive_nn_conv72_stats(P(x), P(w1), P(b1), P(got), 5, 0, DT, P(part), st()) != 0      # an odd batch is refused
     # arguments: rows without a count, aliased output
     assert L.hive_nn_tower72(P(x), P(w), P(bias), P(y), B, nblk, DT, P(y), None, st()) != 0
     assert L.hive_nn_tower72(P(x), P(w), P(bias), P(x), B, nblk, DT, None, None, st()) != 0

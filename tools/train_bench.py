@@ -17,6 +17,7 @@ FLAGS = {"bf16 HIP kernels": {},
          "  weights packed per convolution": {"pack_once": False},
          "  skip gradient added by autograd": {"fuse_skip_grad": False},
          "  head BatchNorms in the library": {"hip_head_bn": False},
+         "  BatchNorm statistics in their own pass": {"fuse_bn_stats": False},
          "  MIOpen weight gradient": {"hip_wgrad": False}}
 
 
@@ -24,6 +25,7 @@ def set_flags(over):
     alpha_net.FusedTrainNet.pack_once = over.get("pack_once", True)
     alpha_net.FusedTrainNet.fuse_skip_grad = over.get("fuse_skip_grad", True)
     alpha_net.FusedTrainNet.hip_head_bn = over.get("hip_head_bn", True)
+    alpha_net.FusedTrainNet.fuse_bn_stats = over.get("fuse_bn_stats", True)
     alpha_net._Conv3x3.hip_wgrad = over.get("hip_wgrad", True)
 
 
@@ -43,7 +45,7 @@ for over in FLAGS.values():
     set_flags(over)
     window(tr, 4)
 res = {k: [] for k in FLAGS}
-for rnd in range(7):
+for rnd in range(11):
     for name, over in FLAGS.items():
         set_flags(over)
         window(tr, 2)
@@ -52,11 +54,11 @@ for rnd in range(7):
 set_flags({})
 for name, v in res.items():
     el = sorted(v)[len(v) // 2]
-    print(f"{name:38s} batch {B}: {el * 1e3:7.2f} ms/step (min {min(v) * 1e3:.2f}, max {max(v) * 1e3:.2f}) = {B / el:8.0f} positions/s = "
+    print(f"{name:42s} batch {B}: {el * 1e3:7.2f} ms/step (min {min(v) * 1e3:.2f}, max {max(v) * 1e3:.2f}) = {B / el:8.0f} positions/s = "
           f"{3 * GFLOP_FWD * B / el / 1e3:6.0f} TFLOP/s (fwd+bwd ~ 3x forward FLOPs)", flush=True)
 del tr
 tr = Trainer(ChessNet().cuda(), autocast_dtype=None)
 window(tr, 3)
 el, loss = window(tr, 5)
-print(f"{'fp32 (libraries)':38s} batch {B}: {el * 1e3:7.2f} ms/step = {B / el:8.0f} positions/s = "
+print(f"{'fp32 (libraries)':42s} batch {B}: {el * 1e3:7.2f} ms/step = {B / el:8.0f} positions/s = "
       f"{3 * GFLOP_FWD * B / el / 1e3:6.0f} TFLOP/s", flush=True)
