@@ -10,14 +10,19 @@ Shape (one workgroup = 4 waves = one wave per SIMD = TWO boards):
     tiles = a[0:255] + v[..] -- every weight fragment fetched from L2 feeds two boards (half the weight stream per MFMA
     of the one-board kernels, 0.31 instead of 0.36 KiB of operands per MFMA);
   * weights (fragment-major, hive_nn.h) go L2 -> VGPR three k-steps ahead through a ring of four 4-fragment buffers; the
-    pixel fragments come from LDS five reads ahead through a ring of six; the 8 k-steps of a tap are unrolled, every LDS
+    pixel fragments come from LDS ten reads ahead through a ring of twelve; the 8 k-steps of a tap are unrolled, every LDS
     offset is an immediate, the per-tap pixel offsets (off-board -> zero pixel) come from a table in .rodata;
   * arithmetic and rounding points are exactly those of resblock_kernel / tower_kernel (hive_nn.hip): fp32 accumulation
     in k order, (acc + bias) [+ skip], max(0, .), one rounding to 16 bits -- the results are bit-identical.
 
 The generator keeps a model of the two in-order memory queues (vmcnt / lgkmcnt) and derives every s_waitcnt from it.
 
-usage: gen_tower_asm.py out.s
+One convolution instead of a tower (kernarg flags, see S_FLAGS below): bit 0 = conv + bias [+ ReLU] -> y (hive_nn_conv72), with
+bit 2 a residual added in the epilogue (hive_nn_conv72_add), with bit 3 the per-channel sums of the output for a BatchNorm
+behind it (hive_nn_conv72_stats): the training step's forward and data-gradient convolutions.
+
+usage: gen_tower_asm.py out.s [debug]     debug builds: 1 = staging identity (LDS image back out), 3 = conv1 + epilogue 1,
+                                          4 = lane constants, 5 = s_memtime stamps per block (tools/dev/t72_*.py)
 """
 import sys
 
@@ -671,9 +676,6 @@ def gen_kernel(name, dt, debug=0):
     c("flags bit 2: one convolution WITH a residual = the second convolution's code on the staged boards and the first weights")
     e("s_bitcmp1_b32 %s, 2" % sr(S_FLAGS))
     e("s_cbranch_scc1 .L%s_twoconv" % name)
-    if debug == 2:
-        c("DEBUG 2: no convolutions -- epilogue 2 on zero accumulators: y = relu(b2 + x)")
-        e("s_branch .L%s_epi2" % name)
     # =============================================================== conv1 + epilogue 1
     conv("c1")
     c("---- epilogue 1: relu(acc + b1) -> 16 bits -> over the boards in LDS")
