@@ -9,10 +9,10 @@
 // 16-lane group, delivered channel-major) -- no transposed copy of the activations is ever made.
 //
 // Decomposition: a workgroup (8 waves) owns the output slice [9 taps][128 k][64 c] and a share of the boards
-// (split-K); a wave owns [9 taps][32 k][32 c] = 36 accumulator tiles (144 VGPRs).  Per board the slice's dY
+// (split-K); a wave owns [9 taps][64 k][16 c] = 36 accumulator tiles (144 VGPRs).  Per board the slice's dY
 // (144 x 128) and X (144 x 64, inside a zero halo so that a tap is a constant address offset) are staged in LDS, double
 // buffered: the next board's LDS-DMA loads (global_load_lds_dwordx4) are issued before the MFMA loop into the other buffer.
-// Per 32-pixel k-step a wave issues 4 + 36 transposed reads for 36 MFMAs (LDS at ~55 % of its rate).
+// Per 32-pixel k-step a wave issues 8 + 18 transposed reads for 36 MFMAs (4 x 1 tiles per tap; 4 + 36 in the 2 x 2 form).
 //   dY image: rows of 256 B, the 32-byte channel block XOR-swizzled with (row & 7); X image: 14 x 20 halo grid, rows of
 //   160 B (128 + 32 pad): any 8 rows that are distinct mod 8 -- which 8 consecutive pixels, shifted by any tap, are on
 //   a 20-wide grid -- hit all 64 banks once: every transposed read is conflict free.
@@ -47,6 +47,15 @@ constexpr int kWgDyBytes = kWgDyRows * kWgDyRow;  // 37,120
 constexpr int kWgXBytes = kWgXRows * kWgXRow;     // 43,840
 constexpr int kWgBuf = kWgDyBytes + kWgXBytes;    // 80,960 per buffer, 161,920 for both (160 KiB = 163,840)
 constexpr int kWgThreads = 512;
+#ifndef HIVE_WG_MT
+#define HIVE_WG_MT 4
+#endif
+// A wave's share of the slice: kWM x kWN accumulator tiles per tap (k x c).  4 x 1: per 32-pixel k-step 8 transposing reads of
+// dY fragments (each feeds 9 MFMAs) and 18 of X fragments (each feeds 4) = 26 reads for 36 MFMAs; the 2 x 2 form of rounds 2-3
+// read 4 + 36 = 40 (an X fragment fed only 2 MFMAs) and was bound by those reads (LDS at its rate before the matrix pipes were).
+constexpr int kWM = HIVE_WG_MT, kWN = 4 / kWM;
+constexpr int kWavesC = kWgCS / (16 * kWN);       // waves side by side along c (4 for 4 x 1, 2 for 2 x 2); the rest along k
+static_assert(kWM * kWN == 4 && (kWgKS / (16 * kWM)) * kWavesC == 8, "eight waves tile the [128 k][64 c] slice");
 constexpr int kWgOut = 9 * 256 * 256;             // entries of dW
 
 __device__ __forceinline__ ws16x4 lds_tr(const unsigned char *lds, unsigned off)
@@ -70,7 +79,7 @@ conv3x3_wgrad_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ DY
     __shared__ __attribute__((aligned(16))) unsigned char lds0[kWgBuf];
     __shared__ __attribute__((aligned(16))) unsigned char lds1[kWgBuf];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wk = wave >> 1, wc = wave & 1;
+    const int wk = wave / kWavesC, wc = wave % kWavesC;
     const int grp = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
 
     // workgroup -> (split, slice): with xcd_order the eight slices of a split are consecutive on ONE XCD
@@ -132,13 +141,13 @@ conv3x3_wgrad_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ DY
         for (int i = 0; i < 10; ++i) stage_span(b, image, i);
     };
 
-    wf32x4 acc[9][2][2];
+    wf32x4 acc[9][kWM][kWN];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < kWM; ++a)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) acc[t][a][c] = wf32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < kWN; ++c) acc[t][a][c] = wf32x4{0.f, 0.f, 0.f, 0.f};
 
     // the MFMA work on one staged board
     // ... during which the spans of the NEXT board (nb >= 0) are sent off a few per k-step: ten LDS-DMA instructions issued
@@ -168,26 +177,26 @@ conv3x3_wgrad_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ DY
             // lane 4 q + p4 of a 16-lane group addresses row q, channels 4 p4 .. 4 p4 + 3 of the block
             unsigned pa = 32u * s + 4u * grp + q, pb = pa + 16u;
             const unsigned ra = pa < 144u ? pa : 144u, rb = pb < 144u ? pb : 144u;        // the zero row beyond the board
-            wbf16x8 A[2];
+            wbf16x8 A[kWM];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const unsigned mb = 2u * wk + mt;
+            for (int mt = 0; mt < kWM; ++mt) {
+                const unsigned mb = (unsigned)(kWM * wk + mt);
                 A[mt] = frag(lds_tr(dyi, ra * kWgDyRow + ((mb ^ (ra & 7u)) << 5) + (p4 << 3)),
                              lds_tr(dyi, rb * kWgDyRow + ((mb ^ (rb & 7u)) << 5) + (p4 << 3)));
             }
             // dY is zero beyond pixel 143, so X only has to be finite there: read pixel 0's neighbourhood
             if (pa >= 144u) pa = 0u;
             if (pb >= 144u) pb = 0u;
-            const unsigned xa = (x_row_of_pixel(pa) - (kWgXW + 1)) * kWgXRow + (2u * wc) * 32u + (p4 << 3);
-            const unsigned xb = (x_row_of_pixel(pb) - (kWgXW + 1)) * kWgXRow + (2u * wc) * 32u + (p4 << 3);
+            const unsigned xa = (x_row_of_pixel(pa) - (kWgXW + 1)) * kWgXRow + (unsigned)(kWN * wc) * 32u + (p4 << 3);
+            const unsigned xb = (x_row_of_pixel(pb) - (kWgXW + 1)) * kWgXRow + (unsigned)(kWN * wc) * 32u + (p4 << 3);
             // B fragments two taps ahead of the MFMAs that consume them (a transposing LDS read takes longer than the two
             // MFMAs the compiler's own schedule left between issue and use); sched_barrier pins the order
-            wbf16x8 Bf[3][2];
+            wbf16x8 Bf[3][kWN];
 #define WG_LOAD_B(tap_)                                                                                              \
     {                                                                                                               \
         const unsigned toff = (unsigned)((((tap_) / 3) * kWgXW + ((tap_) % 3)) * kWgXRow); /* (dy + 1, dx + 1) rows */ \
-        Bf[(tap_) % 3][0] = frag(lds_tr(xi, xa + toff), lds_tr(xi, xb + toff));                                     \
-        Bf[(tap_) % 3][1] = frag(lds_tr(xi, xa + toff + 32u), lds_tr(xi, xb + toff + 32u));                         \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < kWN; ++nt_)                                                        \
+            Bf[(tap_) % 3][nt_] = frag(lds_tr(xi, xa + toff + 32u * nt_), lds_tr(xi, xb + toff + 32u * nt_));         \
     }
             WG_LOAD_B(0)
             WG_LOAD_B(1)
@@ -197,9 +206,9 @@ conv3x3_wgrad_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ DY
                 if (tap + 2 < 9) WG_LOAD_B(tap + 2)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < kWN; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
+                    for (int mt = 0; mt < kWM; ++mt)
                         acc[tap][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt], Bf[tap % 3][nt], acc[tap][mt][nt], 0, 0, 0);
             }
 #undef WG_LOAD_B
@@ -228,14 +237,14 @@ conv3x3_wgrad_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ DY
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < kWM; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < kWN; ++nt) {
                     const wf32x4 v = acc[tap][mt][nt];
 #ifdef HIVE_WG_ABL_NOATOMIC
                     if (v[0] == 12345.678f)
 #endif
-                    out[((tap * 2 + mt) * 2 + nt) * 64] = make_float4(v[0], v[1], v[2], v[3]);
+                    out[((tap * kWM + mt) * kWN + nt) * 64] = make_float4(v[0], v[1], v[2], v[3]);
                 }
     }
 }
@@ -253,9 +262,9 @@ wgrad_reduce_kernel(const float *__restrict__ WS, float *__restrict__ DW, int sp
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
     const int lane = i & 63, tile = (i >> 6) % 36, wave = ((i >> 6) / 36) & 7, slice = (i >> 6) / (36 * 8);
-    const int tap = tile >> 2, mt = (tile >> 1) & 1, nt = tile & 1;
-    const int ks = slice >> 2, cs = slice & 3, wk = wave >> 1, wc = wave & 1, grp = lane >> 4, li = lane & 15;
-    const int k0 = ks * kWgKS + 32 * wk + 16 * mt + 4 * grp, c = cs * kWgCS + 32 * wc + 16 * nt + li;
+    const int tap = tile >> 2, mt = (tile & 3) / kWN, nt = (tile & 3) % kWN;
+    const int ks = slice >> 2, cs = slice & 3, wk = wave / kWavesC, wc = wave % kWavesC, grp = lane >> 4, li = lane & 15;
+    const int k0 = ks * kWgKS + 16 * kWM * wk + 16 * mt + 4 * grp, c = cs * kWgCS + 16 * kWN * wc + 16 * nt + li;
     if (k_major) {                     // [k][tap][c]: the memory of a torch.channels_last nn.Conv2d weight
         float *d = DW + ((long long)k0 * 9 + tap) * 256 + c;
         d[0] = a.x; d[9 * 256] = a.y; d[18 * 256] = a.z; d[27 * 256] = a.w;

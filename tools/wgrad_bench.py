@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SRC = os.path.join(ROOT, "hive-alphazero_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "wg")
-VARIANTS = {"base": ["-DHIVE_WG_DEBUG"], "earlydma": ["-DHIVE_WG_EARLY_DMA"], "noatomic": ["-DHIVE_WG_ABL_NOATOMIC"], "nostage": ["-DHIVE_WG_ABL_NOSTAGE"],
+VARIANTS = {"base": ["-DHIVE_WG_DEBUG"], "tiles2x2": ["-DHIVE_WG_MT=2"], "tiles2x2_nostage_noatomic": ["-DHIVE_WG_MT=2", "-DHIVE_WG_ABL_NOSTAGE", "-DHIVE_WG_ABL_NOATOMIC"],
+            "earlydma": ["-DHIVE_WG_EARLY_DMA"], "noatomic": ["-DHIVE_WG_ABL_NOATOMIC"], "nostage": ["-DHIVE_WG_ABL_NOSTAGE"],
             "nostage_noatomic": ["-DHIVE_WG_ABL_NOSTAGE", "-DHIVE_WG_ABL_NOATOMIC"]}
 
 
