@@ -8,8 +8,9 @@
 // LDS; three of the waves first settle the one-hive question for all pieces of the workgroup on the
 // 22-node piece graph (one lane per piece) and build the per-board placement / next_move_tiles
 // boards; every (board, slot) quad writes its destination board straight to HBM -- the legal set in
-// the reference's pre_actions form; hive_list_kernel turns it into the ascending id list with wave
-// ballots and mbcnt prefix sums when a caller asks for it.
+// the reference's pre_actions form; the same launch (LIST) or hive_list_kernel turns it into the ascending id list with
+// wave ballots and mbcnt prefix sums when a caller asks for it.  Movegen launches of 16,384 boards and more run the same
+// kernel body in the PAIR layout (hive_bb.hpp: a board on two lanes, 32 boards per workgroup; template parameter L).
 //
 // Reference semantics implemented here (paths relative to the reference root):
 //   env_hive.py:196-304   pre_actions / get_actions / encode_action

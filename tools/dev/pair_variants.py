@@ -15,7 +15,8 @@ from hive_alphazero_amd.batch import HIVE_MASK_WORDS  # noqa: E402
 
 
 def main():
-    sizes = [int(a) for a in sys.argv[1:]] or [65536, 1 << 20]
+    all_quad = "--all-quad" in sys.argv[1:]             # time the quad layout of every variant, not only of "base"
+    sizes = [int(a) for a in sys.argv[1:] if a != "--all-quad"] or [65536, 1 << 20]
     h.load()
     base = playout.random_positions(4096, seed=1000)
     st = torch.cuda.current_stream()
@@ -31,12 +32,12 @@ def main():
         m = torch.empty((nb, HIVE_MASK_WORDS), dtype=torch.int32, device="cuda")
         c = torch.empty((nb,), dtype=torch.int32, device="cuda")
         ref = None
-        reps = max(10, min(200, (1 << 22) // nb))
+        reps = max(10, min(400, (1 << 22) // nb))
         times = {}
-        for rnd in range(5):
+        for rnd in range(9):
             for name, L in libs.items():
                 for mode, thr in (("pair", 1), ("quad", 1 << 30)):
-                    if mode == "quad" and name != "base":
+                    if mode == "quad" and name != "base" and not all_quad:
                         continue
                     L.hive_movegen_pair_threshold(thr)
                     a = (ctypes.c_void_p(big.data_ptr()), nb, ctypes.c_void_p(m.data_ptr()), ctypes.c_void_p(c.data_ptr()), None, sp)
