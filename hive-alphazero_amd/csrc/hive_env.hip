@@ -127,34 +127,68 @@ struct PieceInfoT {
     bool on_board, on_top, pinned;
 };
 
+// The per-(board, piece) scalars piece_dests works with, all derived from the staged record and the phase-0 piece info.
+struct PieceScal {
+    unsigned turn, c, h, lv;
+    int stm, color, slot, nq, first_color;
+    bool in_hand, on_board, on_top, stacked, stm_queen;
+};
+__device__ __forceinline__ PieceScal piece_scalars(const uint32_t *st, const uint8_t *pinfo, int q, bool valid)
+{
+    PieceScal s;
+    s.turn = state_byte(st, 33);
+    s.stm = (s.turn & 1u) ? 0 : 1;
+    s.color = q >= 11 ? 1 : 0;
+    s.slot = q - 11 * s.color;
+    s.c = state_byte(st, (unsigned)q);
+    s.in_hand = s.c >= (unsigned)kCells;
+    // stack height of the mover's cell and the mover's index in it (env_hive.py:213), from phase 0
+    const unsigned pi = pinfo[q];
+    s.h = pi & 15u;
+    s.lv = pi >> 4;
+    s.on_board = valid && !s.in_hand;
+    s.on_top = s.on_board && (s.lv + 1u == s.h);
+    s.stacked = s.h > 1u;
+    const bool wq = state_byte(st, 0u) < (unsigned)kCells;         // white queen placed
+    const bool bq = state_byte(st, 11u) < (unsigned)kCells;        // black queen (piece 11) placed
+    s.nq = (wq ? 1 : 0) + (bq ? 1 : 0);
+    s.first_color = wq ? 0 : 1;
+    s.stm_queen = s.stm == 0 ? wq : bq;
+    return s;
+}
+
+template <class L>
+__device__ __forceinline__ PieceInfoT<typename L::B> piece_finish(const PieceScal s, const uint32_t *st, const uint32_t *occ_p,
+                                                                  const uint32_t *place_p, int q, int type, bool own, bool valid,
+                                                                  bool pinned, typename L::B rule, typename L::B occ_in,
+                                                                  typename L::B srcbit_in, typename L::B nsrc_in);
+
 // Everything one (board, piece) quad computes; scalars are replicated over the quad's lanes.
 // `type` and the loops' trip tests are wave-uniform.
 // own == true : get_actions semantics (env_hive.py:207-285)
 // own == false: mini_black_actions semantics for an enemy piece (env_hive.py:449-485)
-template <int ANT_STEPS, class L = QuadLay>
-__device__ __forceinline__ PieceInfoT<typename L::B> piece_dests(const uint32_t *st, const uint32_t *occ_p, const uint8_t *pinfo, const uint32_t *pinmask_p, const int *pin_done_p,
-                                                 const uint32_t *place_p, int q, int type, bool own, bool valid)
+// What piece_dests reads of its (board, piece): LDS addresses of the board's staged data, the piece index, validity.
+struct PieceArgs {
+    const uint32_t *st, *occ_p;
+    const uint8_t *pinfo;
+    const uint32_t *pinmask_p, *place_p;
+    int q;
+    bool valid;
+};
+
+// late(): the same PieceArgs built AGAIN from scratch (pair layout only; see piece_finish)
+template <int ANT_STEPS, class L = QuadLay, class Late>
+__device__ __forceinline__ PieceInfoT<typename L::B> piece_dests(const PieceArgs a, const int *pin_done_p, int type, bool own, Late late)
 {
     using BB = typename L::B;
+    const uint32_t *st = a.st, *occ_p = a.occ_p, *pinmask_p = a.pinmask_p, *place_p = a.place_p;
+    const uint8_t *pinfo = a.pinfo;
+    const int q = a.q;
+    const bool valid = a.valid;
     PieceInfoT<BB> out;
-    const unsigned turn = state_byte(st, 33);
-    const int stm = (turn & 1u) ? 0 : 1;
-    const int color = q >= 11 ? 1 : 0, slot = q - 11 * color;
-    const unsigned c = state_byte(st, (unsigned)q);
-    const bool in_hand = c >= (unsigned)kCells;
-
-    // stack height of the mover's cell and the mover's index in it (env_hive.py:213), from phase 0
-    const unsigned pi = pinfo[q];
-    const unsigned h = pi & 15u, lv = pi >> 4;
-    const bool on_board = valid && !in_hand;
-    const bool on_top = on_board && (lv + 1u == h);
-    const bool stacked = h > 1u;
-
-    const bool wq = state_byte(st, 0u) < (unsigned)kCells;         // white queen placed
-    const bool bq = state_byte(st, 11u) < (unsigned)kCells;        // black queen (piece 11) placed
-    const int nq = (wq ? 1 : 0) + (bq ? 1 : 0);
-    const int first_color = wq ? 0 : 1;
-    const bool stm_queen = stm == 0 ? wq : bq;
+    const PieceScal s0 = piece_scalars(st, pinfo, q, valid);
+    const unsigned c = s0.c;
+    const bool on_board = s0.on_board, on_top = s0.on_top, stacked = s0.stacked;
 
     const BB occ = L::load(occ_p);
     const BB srcbit = L::bit(on_board ? c : 255u);
@@ -259,9 +293,36 @@ __device__ __forceinline__ PieceInfoT<typename L::B> piece_dests(const uint32_t 
     // the verdict of the pin waves (they run concurrently with the loops above and are much shorter)
     while (__hip_atomic_load(pin_done_p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kPinWaves)
         __builtin_amdgcn_s_sleep(1);
-    const bool pinned = ((*pinmask_p >> q) & 1u) != 0u;
-    const bool movable = on_top && !pinned;
+    if constexpr (kLate) {
+        const PieceArgs b = late();
+        const bool pinned = ((*b.pinmask_p >> b.q) & 1u) != 0u;
+        return piece_finish<L>(piece_scalars(b.st, b.pinfo, b.q, b.valid), b.st, b.occ_p, b.place_p, b.q, type, own, b.valid, pinned,
+                               rule, L::zero(), L::zero(), L::zero());
+    } else {
+        const bool pinned = ((*pinmask_p >> q) & 1u) != 0u;
+        return piece_finish<L>(s0, st, occ_p, place_p, q, type, own, valid, pinned, rule, occ, srcbit, nsrc);
+    }
+}
 
+// The tail of piece_dests: the piece's rule result -> its destination board (turn gates, placement, domains).  Pair layout:
+// called with the scalars derived AGAIN behind the pin wait (an acquire: the LDS loads are made again), so that none of them
+// is carried -- in this layout: spilled -- through the flood loops; occ, srcbit and nsrc are rebuilt likewise.
+template <class L>
+__device__ __forceinline__ PieceInfoT<typename L::B> piece_finish(const PieceScal s, const uint32_t *st, const uint32_t *occ_p,
+                                                                  const uint32_t *place_p, int q, int type, bool own, bool valid,
+                                                                  bool pinned, typename L::B rule, typename L::B occ_in,
+                                                                  typename L::B srcbit_in, typename L::B nsrc_in)
+{
+    using BB = typename L::B;
+    constexpr bool kLate = L::kLanes == 2;
+    PieceInfoT<BB> out;
+    const unsigned turn = s.turn, c = s.c, h = s.h, lv = s.lv;
+    const int color = s.color, slot = s.slot, nq = s.nq, first_color = s.first_color;
+    const bool in_hand = s.in_hand, on_board = s.on_board, on_top = s.on_top, stm_queen = s.stm_queen;
+    const bool movable = on_top && !pinned;
+    auto load_nsrc = [&]() { return on_board ? L::load(d_tables.nmask[c]) : L::zero(); };
+    const BB srcbit = kLate ? L::bit(on_board ? c : 255u) : srcbit_in;
+    const BB nsrc = nsrc_in, occ = occ_in;
 
     // ---- turn gating (move_checker.py:38-55)
     bool gate = true;
@@ -625,8 +686,17 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
     bool own;
     if (!FULL) { q = stm * 11 + wv; own = true; }
     else { int col = item >> 3; q = col * 11 + wv; own = (col == stm); }
-    PieceInfoT<BB> pc = piece_dests<(L::kLanes == 2 ? HIVE_PAIR_ANT_STEPS : HIVE_ANT_STEPS), L>(st, sm.occ[bl], sm.pinfo[bl], &sm.pinmask[bl], &sm.pin_done, sm.place[bl], q,
-                                                           type, own, valid);
+    const PieceArgs pa{st, sm.occ[bl], sm.pinfo[bl], &sm.pinmask[bl], sm.place[bl], q, valid};
+    // (pair layout: the tail of the piece work builds these again from the thread id instead of carrying -- spilling -- them
+    // through the flood loops; the empty asm keeps the compiler from recognising the value it already has)
+    auto late_args = [&]() -> PieceArgs {
+        int b2 = (int)(threadIdx.x & 63u) >> L::kShift;
+        asm volatile("" : "+v"(b2));
+        const uint32_t *st2 = sm.state[b2];
+        const int stm2 = (state_byte(st2, 33) & 1u) ? 0 : 1;
+        return PieceArgs{st2, sm.occ[b2], sm.pinfo[b2], &sm.pinmask[b2], sm.place[b2], stm2 * 11 + wv, gbase + b2 < n};
+    };
+    PieceInfoT<BB> pc = piece_dests<(L::kLanes == 2 ? HIVE_PAIR_ANT_STEPS : HIVE_ANT_STEPS), L>(pa, &sm.pin_done, type, own, late_args);
     HIVE_STAMP(1);
     if (own && (mask != nullptr || count != nullptr)) {
         // the legal set leaves as it is: slot wv's destination board, two words per lane, straight to HBM
@@ -635,8 +705,10 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
             *reinterpret_cast<uint2 *>(mask + (gbase + bl) * HIVE_MASK_WORDS + wv * 6 + 2 * (lane & 3)) =
                 make_uint2(pc.D.lo, pc.D.hi);
         } else {
-            if (valid && mask != nullptr) {      // three words per lane (12-byte pieces, 4-byte aligned)
-                uint32_t *mp = mask + (gbase + bl) * HIVE_MASK_WORDS + wv * 6 + 3 * (lane & 1);
+            int b3 = (int)(threadIdx.x & 63u) >> L::kShift;      // (built again, like late_args above)
+            asm volatile("" : "+v"(b3));
+            if (gbase + b3 < n && mask != nullptr) {      // three words per lane (12-byte pieces, 4-byte aligned)
+                uint32_t *mp = mask + (gbase + b3) * HIVE_MASK_WORDS + wv * 6 + 3 * (int)(threadIdx.x & 1u);
                 mp[0] = pc.D.w0; mp[1] = pc.D.w1; mp[2] = pc.D.w2;
             }
         }
@@ -648,7 +720,9 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
                 if (pc.D.hi) atomicOr(&lm.any[bl][2 * (lane & 3) + 1], pc.D.hi);
             }
             } else {
-                uint32_t *dp = &lm.dest[bl][wv][3 * (lane & 1)], *ap = &lm.any[bl][3 * (lane & 1)];
+                int b5 = (int)(threadIdx.x & 63u) >> L::kShift;
+                asm volatile("" : "+v"(b5));
+                uint32_t *dp = &lm.dest[b5][wv][3 * (int)(threadIdx.x & 1u)], *ap = &lm.any[b5][3 * (int)(threadIdx.x & 1u)];
                 dp[0] = pc.D.w0; dp[1] = pc.D.w1; dp[2] = pc.D.w2;
                 if (pc.D.w0) atomicOr(ap, pc.D.w0);
                 if (pc.D.w1) atomicOr(ap + 1, pc.D.w1);
@@ -656,7 +730,13 @@ hive_piece_kernel(const HiveBoard *__restrict__ boards, int n, uint32_t *__restr
             }
         }
         const int nd = bb_popc_lane(pc.D);                      // destination sets of different pieces are disjoint
-        if (nd) atomicAdd(&sm.nlegal[bl], nd);
+        if constexpr (L::kLanes == 4) {
+            if (nd) atomicAdd(&sm.nlegal[bl], nd);
+        } else {
+            int b4 = (int)(threadIdx.x & 63u) >> L::kShift;
+            asm volatile("" : "+v"(b4));
+            if (nd) atomicAdd(&sm.nlegal[b4], nd);
+        }
     }
     HIVE_STAMP(2);
 
