@@ -360,6 +360,7 @@ class FusedTrainNet(nn.Module):
     hip_head_bn = True       # the heads' BatchNorm2d(1) / BatchNorm2d(128) + ReLU on the HIP kernels too
     fuse_skip_grad = True    # a block input's two gradients (conv1's data gradient + the skip's) summed in the convolution launch
     fuse_bn_stats = True     # a tower convolution adds up the statistics of the BatchNorm behind it (no separate pass over its output)
+    keep_tower_output = False  # tests: keep the last forward's tower output (res_18's result) in self.tower_output
 
     def __init__(self, net, hip_conv=True):
         super().__init__()
@@ -415,8 +416,11 @@ class FusedTrainNet(nn.Module):
             out = bn_act(conv(s, blk.conv1, *pk(2 * i), link=link, stats=st1), blk.bn1, track=False, stats=st1)
             s = bn_act(conv(out, blk.conv2, *pk(2 * i + 1), stats=st2), blk.bn2, residual=s, track=False, link=link, stats=st2)
             counters += [blk.bn1.num_batches_tracked, blk.bn2.num_batches_tracked]
+        if self.keep_tower_output:
+            self.tower_output = s.detach()
         out, hb = net.outblock, self.hip_head_bn
-        v = out.conv(s)                            # OutBlock.forward (alpha_net.py:67-80) with the two BatchNorms on the HIP kernels
+        # OutBlock.forward (alpha_net.py:67-80) with the two BatchNorms on the HIP kernels
+        v = out.conv(s)
         pl = out.conv1(s)
         if hb and bn_act_ok(v) and bn_act_ok(pl):
             v = bn_act(v, out.bn, track=False)

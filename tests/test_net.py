@@ -488,8 +488,7 @@ def test_hip_weights_packed_in_one_launch_equal_the_single_packs(weights_cl):
         tr = A.Trainer(net)
         assert isinstance(tr.model, A.FusedTrainNet)
         tr.model.pack_once = once
-        acts = []
-        hook = net.outblock.conv.register_forward_pre_hook(lambda mod, inp: acts.append(inp[0].detach().clone()))   # the tower's output
+        tr.model.keep_tower_output = True
         gg = torch.Generator(device="cuda").manual_seed(9)
         x = (torch.rand((16, 56, 12, 12), device="cuda", generator=gg) < 0.1).float()
         pol = torch.softmax(torch.randn((16, 1584), device="cuda", generator=gg), dim=1)
@@ -497,8 +496,7 @@ def test_hip_weights_packed_in_one_launch_equal_the_single_packs(weights_cl):
         tr.model.train()
         loss = tr.loss(x, pol, val)
         loss.backward()
-        hook.remove()
-        res[once] = (loss.detach().clone(), {k: p_.grad.clone() for k, p_ in net.named_parameters()}, acts[0])
+        res[once] = (loss.detach().clone(), {k: p_.grad.clone() for k, p_ in net.named_parameters()}, tr.model.tower_output.clone())
     assert torch.equal(res[True][2], res[False][2])
     assert abs(res[True][0].item() - res[False][0].item()) <= 1e-5
     for k, a in res[True][1].items():
