@@ -860,6 +860,13 @@ def main():
                          "traffic_source": None if ctr is None else f"{ctr['file']}: {ctr['source']} (separate rocprofv3 --pmc "
                                            "passes of this command, gfx950 FETCH_SIZE correction applied; not measurable in-run)",
                          "kernel": "hive_piece_kernel<false>", "launch_us": round(launch_us, 3),
+                         "valu_issue_roof": None if ctr is None else {
+                             "valu_wave_instr_per_board": round(ctr["valu_per_board"], 1),
+                             "peak_Mboards_per_s": round(ctr["valu_issue_peak_mboards"], 1),
+                             "frac": round(n / launch_us / ctr["valu_issue_peak_mboards"], 4),
+                             "note": "the bound that applies: 1024 SIMDs x 2.4 GHz / (4 cycles x VALU wave-instructions per board); "
+                                     "a 4096-board launch is one 11-wave workgroup per CU, its time the busiest SIMD's issue time "
+                                     "plus staging and the dispatch ramp"},
                          "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_BOARD,
                          "note": "VALU-issue bound (~489 wave-instructions per board in this launch's quad layout), not HBM bound: see saturated.valu_issue_roof; "
                                  "4096 boards = 256 workgroups x 11 waves = one workgroup per CU; the 256 KB corpus is re-read "
